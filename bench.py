@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""rt355 benchmark: Mrays/s (primary + reflection + shadow) at 1080p, depth 5.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|t64|c3|c1]
+
+One "step" = one batch of ``--frames`` (default 16) 1080p frames of BASELINE.json config 2
+(1920x1080, 8-sphere scene, depth 5, 13 shadow rays per shaded hit, keyed RNG, seed = frame
+index), inputs (scene) already resident on the GPU.  With N > 1 ranks (one process per GPU,
+launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
+(tile t -> rank t mod N), each rank renders its tiles of all frames of the batch, and ONE RCCL
+gather per step moves the packed tiles to GPU 0, where rt_scatter_rows puts them in image order:
+total work per step is fixed => "strong" scaling.  Rays are counted by the kernel itself
+(rt_get_ray_counts), not modelled.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — FP32-VALU roofline of rt_render_kernel from algorithmic flops and
+                 the kernel's live HIP-event duration on its launch stream;
+  cpu_baseline — the FP64 C++ restatement of the reference (oracle/, "port") timed on this
+                 host's cores on a bounded row sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 core (cannot run here)
+
+WORKLOADS = {
+    # name: (width, height, n_spheres, scene seed, keep_default, max_depth, description)
+    "c1": (640, 480, 3, 0, True, 3, "config 1: default 3-sphere scene 640x480 depth 3"),
+    "c2": (1920, 1080, 8, 1, True, 5, "config 2: 1920x1080, 8-sphere scene, depth 5, shadow rays"),
+    "t64": (1920, 1080, 64, 2, False, 5, "north-star target: 1920x1080, 64 spheres, depth 5"),
+    "c3": (3840, 2160, 64, 2, False, 8, "config 3: 3840x2160, 64 spheres, depth 8"),
+}
+
+
+def algorithmic_flops(rays: int, shaded: int, n_spheres: int, area_samples: int) -> float:
+    """SURVEY.md §8d, conservative: 5 + 17*N per ray (the 3 flops per candidate root are not
+    counted), plus per shaded hit 30 (point, normal) + (1 + samples) * 75 (light dir, offset origin,
+    diffuse, R, V.R, pow-50, accumulate) + 25 (reflect + mix)."""
+    return rays * (5.0 + 17.0 * n_spheres) + shaded * (30.0 + (1 + area_samples) * 75.0 + 25.0)
+
+
+def build_scene(wl):
+    from raytracer_amd.scenes import default_scene, generate_scene
+    w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
+    return default_scene() if n == 3 else generate_scene(n, sseed, w, h, keep_default=keep)
+
+
+def cpu_baseline(wl, target_s=15.0):
+    """Time the oracle (FP64 restatement of the reference) on this host, all cores, on every k-th
+    row of one frame of the same workload."""
+    import numpy as np
+    from oracle import cpu_oracle
+    w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
+    scene = build_scene(wl)
+    threads = min(cpu_oracle.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 10**6,
+                  len(os.sched_getaffinity(0)))
+
+    def run(rows):
+        px = np.stack([np.tile(np.arange(w), len(rows)), np.repeat(rows, w)], 1)
+        t0 = time.perf_counter()
+        o = cpu_oracle.render_scene(scene, w, h, pixels=px, max_depth=D, mode="K", seed=0, threads=threads)
+        dt = time.perf_counter() - t0
+        rays = int(o["trace_levels"].sum()) + 13 * int(o["hit_levels"].sum())
+        return rays, dt
+
+    probe_rows = np.arange(0, h, max(1, h // 16))
+    rays, dt = run(probe_rows)
+    per_row = dt / len(probe_rows)
+    k = int(min(h, max(len(probe_rows), target_s / max(per_row, 1e-9))))
+    rows = np.unique(np.linspace(0, h - 1, k).astype(int))
+    rays, dt = run(rows)
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
+                sample=f"{len(rows)} of {h} rows of one frame ({rays} rays, {dt:.1f} s), FP64, OpenMP",
+                python_reference_mrays_1core=PY_REFERENCE_MRAYS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=16, help="frames per step (batch)")
+    ap.add_argument("--samples", type=int, default=1)
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: rt355 has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from raytracer_amd.distributed import gather_row_tiles
+    from raytracer_amd.render import Renderer
+    from raytracer_amd.scenes import pack_scene
+    from raytracer_amd import tiling
+
+    w, h, n_sph, _, _, D, desc = WORKLOADS[args.workload]
+    F, tr = args.frames, args.tile_rows
+    scene = build_scene(args.workload)
+    packed = pack_scene(scene)
+    r = Renderer(local_rank)
+    r.upload_scene(packed)
+
+    rows_max = tiling.max_local_rows(h, tr, world)
+    slab_bytes = rows_max * w * 3
+    dev = f"cuda:{local_rank}"
+    # this rank's packed tiles of the F frames of a step (N > 1 only)
+    slab = torch.zeros((F, slab_bytes), dtype=torch.uint8, device=dev) if world > 1 else None
+    if rank == 0:
+        gathered = torch.empty((world, F, slab_bytes), dtype=torch.uint8, device=dev) if world > 1 else None
+        frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i, timed_idx=None):
+        if timed_idx is not None:
+            ev[timed_idx][0].record()
+        for f in range(F):
+            # N = 1: the rank owns every row, so its packed slab IS the frame
+            out = frames_out[f] if world == 1 else slab[f].view(rows_max, w, 3)
+            r.render_rows(w, h, args.samples, tile_rows=tr, tile_first=rank, tile_stride=world,
+                          max_depth=D, rng_mode="K", seed=i * F + f, out=out)
+        if timed_idx is not None:
+            ev[timed_idx][1].record()
+        if world > 1:
+            dist.gather(slab, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                for f in range(F):
+                    r.scatter_rows(gathered[:, f], world, w, h, tr, out=frames_out[f])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    r.reset_ray_counts()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, i)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    rc = r.ray_counts()
+    stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * F)        # per render launch
+    kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    total_rays, shaded, primary = (float(x) for x in stats.tolist())
+    dt = float(tmax.item())
+
+    if rank == 0:
+        # per-launch (per rank) algorithmic flops of rt_render_kernel on rank 0
+        launches = args.steps * F
+        fl = algorithmic_flops(rc["total"], rc["shaded_hits"], n_sph, packed.area_samples) / launches
+        achieved = fl / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 1080p depth 5",
+            "value": total_rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{desc}; batch of {F} frames per step, {args.samples} spp, "
+                                   f"keyed RNG, {n_sph} spheres, 12 area-light samples",
+                       "width": w, "height": h, "max_depth": D, "frames_per_step": F,
+                       "parallelism": f"row-tiles x{world} (tile {tr} rows) + RCCL gather to GPU 0"
+                       if world > 1 else "single GPU"},
+            "rays_per_frame": total_rays / (args.steps * F),
+            "rays_per_pixel": total_rays / max(primary, 1.0),
+            "mpixels_per_s": primary / dt / 1e6,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "rt_render_kernel", "kernel_ms": kern_ms,
+                         "flops_per_launch": fl,
+                         "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d; "
+                                 "HBM traffic is the framebuffer only (3 B/pixel)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

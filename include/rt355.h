@@ -1,0 +1,141 @@
+/* rt355 — C ABI of the MI355X-native sphere ray tracer (librt355.so).
+ *
+ * This is the drop-in boundary for the per-pixel render path of aram-ap/RayTracer's
+ * raytracer.py.  The reference has no FFI: its boundary is the Python function
+ * render(width, height, samples) (raytracer.py:310-325) reading the module-global `scene`
+ * (raytracer.py:78-87).  The Python host in raytracer_amd/ keeps that entry point and calls
+ * the functions below through ctypes; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success and a negative RT_E* code on
+ *     failure, with a message retrievable by rt_last_error(); no C++ exception crosses the ABI.
+ *   - the caller owns every buffer.  `out_*` pointers are DEVICE pointers on the context's GPU
+ *     (e.g. torch.Tensor.data_ptr()); scene/camera/light inputs are HOST pointers.
+ *   - launches are asynchronous on the context's stream (rt_set_stream); rt_synchronize() or
+ *     the caller's own stream sync completes them.  One host thread per context.
+ *   - the library never falls back to a CPU path: without a gfx950 GPU rt_create fails.
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_MAX_SPHERES 4096      /* 16 B of LDS per sphere -> 64 KiB at the limit            */
+#define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
+#define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
+
+#define RT_OK 0
+#define RT_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned)          */
+#define RT_EDEVICE (-2)  /* no usable GPU / HIP runtime error                                   */
+#define RT_ESTATE (-3)   /* call order (e.g. render before rt_upload_scene)                     */
+
+/* RNG replacement for random.random() (raytracer.py:180-181, 293-294).  The reference draws
+ * from Python's global Mersenne Twister in call order, which no parallel renderer can
+ * reproduce; both modes are pure functions of position. */
+#define RT_RNG_CONSTANT 0 /* every draw is 0.5: pixel-centre rays, area light at its centre     */
+#define RT_RNG_KEYED 1    /* hash of (seed, x, y, sample, level, draw) — see DESIGN.md §RNG      */
+
+typedef struct rt_ctx rt_ctx;
+
+/* Pinhole camera.  The reference hard-codes origin 0, direction normalize((u, v, -1))
+ * (raytracer.py:293-295); this is that with right=(1,0,0), up=(0,1,0), forward=(0,0,-1). */
+typedef struct rt_camera {
+  float origin[3];
+  float right[3];
+  float up[3];
+  float forward[3];
+} rt_camera;
+
+/* scene['global_light'] (Light, raytracer.py:62-66, :79) and scene['area_light']
+ * (AreaLight, raytracer.py:68-75, :80). */
+typedef struct rt_lights {
+  float point_pos[3];
+  float point_color[3];
+  float point_intensity;
+  float area_pos[3];
+  float area_u[3];
+  float area_v[3];
+  float area_color[3];
+  float area_intensity;
+  int32_t area_samples;
+} rt_lights;
+
+/* Create / destroy a context bound to one GPU (one process per GPU; multi-GPU runs create one
+ * context per rank).  Replaces nothing in the reference (it has no device). */
+int rt_create(int device_id, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+
+/* Message for the last failure on this context (ctx may be NULL for rt_create failures). */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Use the caller's HIP stream (hipStream_t passed as void*; NULL = the context's own stream). */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+int rt_synchronize(rt_ctx* ctx);
+
+/* Upload scene['spheres'] as struct-of-arrays plus the two lights.
+ * Replaces the reference's AoS Python objects Sphere/Material (raytracer.py:42-54) and the
+ * `scene` dict (raytracer.py:78-87).
+ *   geom4[n][4] = cx, cy, cz, radius^2      mat4[n][4] = R, G, B, reflection     spec[n] = specular
+ * All host pointers; 0 <= n <= RT_MAX_SPHERES; 1 <= area_samples <= RT_MAX_AREA_SAMPLES. */
+int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const float* spec,
+                    int n_spheres, const rt_lights* lights);
+
+/* render(width, height, samples) (raytracer.py:310-325): the whole frame.
+ *   out_rgb: device uint8 [height][width][3], row 0 = top, tightly packed — the array the
+ *            reference returns and hands to glTexImage2D (raytracer.py:346).
+ *   out_hit: device int32 [height][width] primary hit sphere index of the last sample (-1 =
+ *            miss), or NULL.
+ *   max_depth D: trace_ray's literal `depth > 5` (raytracer.py:233) as a parameter; D = 5 is
+ *            the reference. */
+int rt_render(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
+              int max_depth, int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit);
+
+/* Row-tile variant for multi-GPU sharding: renders row tiles t = tile_first, tile_first +
+ * tile_stride, ... (tile t covers image rows [t*tile_rows, min((t+1)*tile_rows, height))) and
+ * writes them packed, in that order, to out_rgb [n_local_rows][width][3] (and out_hit likewise).
+ * The live equivalent of the reference's unused render_chunk tile split (raytracer.py:299-308).
+ * *n_local_rows_out (nullable) receives the number of rows written. */
+int rt_render_rows(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
+                   int max_depth, int rng_mode, uint64_t seed, int tile_rows, int tile_first,
+                   int tile_stride, uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out);
+
+/* render_chunk((x_start, x_end, y_start, y_end, width, height, scene, samples))
+ * (raytracer.py:299-308): clamped, UNquantised colour of a sub-rectangle.
+ *   out_rgbf: device float32 [y_end-y_start][x_end-x_start][3]  (the reference returns float64) */
+int rt_render_chunk(rt_ctx* ctx, const rt_camera* cam, int x_start, int x_end, int y_start,
+                    int y_end, int width, int height, int samples, int max_depth, int rng_mode,
+                    uint64_t seed, float* out_rgbf);
+
+/* Animation batch (BASELINE.json config 5): n_frames renders of one uploaded scene, frame f with
+ * cams[f] and seeds[f], into out_rgb [n_frames][height][width][3].  No reference counterpart
+ * beyond calling render() in a loop. */
+int rt_render_frames(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames,
+                     int width, int height, int samples, int max_depth, int rng_mode,
+                     uint8_t* out_rgb);
+
+/* Place row tiles gathered from `n_ranks` ranks back into image order (on the root GPU, after
+ * the RCCL gather).  gathered: device uint8 [n_ranks][rank_stride_bytes], rank r's slab holding
+ * its packed rows as written by rt_render_rows(tile_first = r, tile_stride = n_ranks).
+ * out_rgb: device uint8 [height][width][3]. */
+int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_bytes, int n_ranks,
+                    int width, int height, int tile_rows, uint8_t* out_rgb);
+
+/* Ray statistics accumulated by every render call since the last reset (device counters; this
+ * call synchronises the stream).  out[0] = primary rays, out[1] = reflection rays,
+ * out[2] = shadow rays, out[3] = shaded hits (compute_lighting calls).  A "ray" is one
+ * find_nearest_intersection-equivalent scan (raytracer.py:152-172), SURVEY.md §8d. */
+int rt_get_ray_counts(rt_ctx* ctx, uint64_t out[4]);
+int rt_reset_ray_counts(rt_ctx* ctx);
+
+/* Build/ABI information. */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

@@ -1,0 +1,295 @@
+// TEST INFRASTRUCTURE ONLY. CPU restatement of the reference's per-pixel render path
+// (/root/reference/raytracer.py), used as the parity checker by tests/, by
+// __graft_entry__.smoke() and as bench.py's cpu_baseline ("port").  The product path
+// (raytracer_amd/) never links, loads or calls this file.
+//
+// Pinning: this restatement is checked against the reference ITSELF, imported in the build
+// container by oracle/ref_harness.py (golden vectors committed under tests/golden/, generator
+// oracle/gen_golden.py).  In double precision it reproduces the reference's FP64 results
+// bit-for-bit on those vectors: every expression below keeps the reference's operation order,
+// uses libm pow() where the reference writes `**` (CPython float_pow calls the same libm pow),
+// and the file must be compiled with -ffp-contract=off so no FMA is formed.
+//
+// The float instantiation (precision=1) is a diagnostic: it predicts which pixels an FP32
+// implementation may legitimately decide differently (grazing rays), it is not an oracle.
+//
+// Each function cites the reference lines it follows.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+template <typename T>
+struct V3 {  // raytracer.py:10-35
+  T x, y, z;
+};
+template <typename T> inline V3<T> add(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }   // :16-17
+template <typename T> inline V3<T> sub(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }   // :19-20
+template <typename T> inline V3<T> mulv(V3<T> a, V3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }  // :23-24
+template <typename T> inline V3<T> muls(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }            // :25
+template <typename T> inline T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // :30-31
+template <typename T> inline T sq(T v) { return std::pow(v, T(2)); }                                      // `**2`
+template <typename T> inline V3<T> normalize(V3<T> a) {                                                   // :33-35
+  T len = std::sqrt(sq(a.x) + sq(a.y) + sq(a.z));
+  return {a.x / len, a.y / len, a.z / len};
+}
+
+template <typename T>
+struct SceneT {
+  int n = 0;
+  std::vector<V3<T>> center, color;
+  std::vector<T> radius, specular, reflection;
+  V3<T> p_pos, p_col; T p_int;                       // scene['global_light'], :79
+  V3<T> a_pos, a_u, a_v, a_col; T a_int; int a_samples;  // scene['area_light'], :80
+  V3<T> cam_o, cam_r, cam_u, cam_f;
+};
+
+// ---- keyed RNG (definition: oracle/ref_harness.py docstring) -------------------------------
+inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+inline uint32_t mix(uint32_t h, uint32_t v) { return fmix32(h + 0x9E3779B9u + v); }
+struct Rng {
+  int mode;           // 0 = constant 0.5 (mode C), 1 = keyed (mode K)
+  uint32_t pixel_key;
+  double draw(uint32_t level, uint32_t i) const {
+    if (mode == 0) return 0.5;
+    uint32_t lk = mix(pixel_key, level);
+    return double(fmix32(lk + i * 0x9E3779B9u + 0x7F4A7C15u) >> 8) * (1.0 / 16777216.0);
+  }
+};
+
+struct PixelStats {
+  int primary_hit = -1;
+  int64_t trace_levels = 0, hit_levels = 0;
+  double margin = std::numeric_limits<double>::infinity();
+};
+
+// intersect_sphere, raytracer.py:93-104. Returns false for `None`.
+template <typename T>
+inline bool intersect_sphere(V3<T> o, V3<T> d, V3<T> c, T radius, T* t_out, double* margin) {
+  V3<T> oc = sub(o, c);                       // :94
+  T a = dot(d, d);                            // :95
+  T b = T(2) * dot(oc, d);                    // :96
+  T cc = dot(oc, oc) - sq(radius);            // :97
+  T disc = sq(b) - T(4) * a * cc;             // :98
+  if (margin) {
+    double m = std::fabs(double(disc)) / std::fmax(1.0, double(b) * double(b));
+    if (m < *margin) *margin = m;
+  }
+  if (disc < 0) return false;                 // :99-100
+  T t = (-b - std::sqrt(disc)) / (T(2) * a);  // :101
+  if (t < 0) return false;                    // :102-103
+  *t_out = t;
+  return true;
+}
+
+template <typename T>
+struct Hit { int idx; V3<T> point, normal; };
+
+// find_nearest_intersection, raytracer.py:152-172 (spheres only: :156 iterates scene['spheres'])
+template <typename T>
+inline bool find_nearest(const SceneT<T>& s, V3<T> o, V3<T> d, Hit<T>* h, double* margin) {
+  bool found = false;
+  T min_distance = std::numeric_limits<T>::infinity();   // :154
+  T second = std::numeric_limits<T>::infinity();
+  for (int i = 0; i < s.n; ++i) {                         // :156
+    T t;
+    if (!intersect_sphere(o, d, s.center[i], s.radius[i], &t, margin)) continue;
+    if (margin && t != T(0)) { if (t < min_distance) second = min_distance; else if (t < second) second = t; }
+    if (t != T(0) && t < min_distance) {                  // :162  `if t and t < min_distance`
+      min_distance = t;
+      V3<T> p = add(o, muls(d, t));                       // :165
+      h->idx = i; h->point = p;
+      h->normal = normalize(sub(p, s.center[i]));         // :166, :139-140
+      found = true;
+    }
+  }
+  if (margin && found && std::isfinite(double(second))) {
+    double gap = (double(second) - double(min_distance)) / std::fmax(1e-30, double(min_distance));
+    if (gap < *margin) *margin = gap;
+  }
+  return found;
+}
+
+template <typename T>
+inline T max0(T v) { return v > 0 ? v : T(0); }           // max(0, v)
+
+// compute_lighting, raytracer.py:174-211
+template <typename T>
+V3<T> compute_lighting(const SceneT<T>& s, V3<T> point, V3<T> normal, V3<T> view, int mat,
+                       const Rng& rng, uint32_t level) {
+  V3<T> color{0, 0, 0};
+  Hit<T> sh;
+  T spec_k = s.specular[mat];
+  // --- scene['global_light'] (point light), :197-209 ---
+  {
+    V3<T> ldir = normalize(sub(s.p_pos, point));                          // :198
+    V3<T> so = add(point, muls(normal, T(0.001)));                        // :199
+    if (!find_nearest(s, so, ldir, &sh, (double*)nullptr)) {              // :200-202 (refraction == 0)
+      T diffuse = max0(dot(normal, ldir));                                // :203
+      color = add(color, muls(muls(mulv(s.color[mat], s.p_col), s.p_int), diffuse));  // :204
+      if (spec_k > 0) {                                                   // :206
+        V3<T> r = sub(ldir, muls(normal, T(2) * dot(ldir, normal)));      // :207
+        T sp = std::pow(max0(dot(view, r)), T(50));                       // :208
+        color = add(color, muls(muls(muls(s.p_col, s.p_int), spec_k), sp));  // :209
+      }
+    }
+  }
+  // --- scene['area_light'], :177-196 ---
+  {
+    V3<T> contrib{0, 0, 0};
+    for (int k = 0; k < s.a_samples; ++k) {                               // :179
+      T ru = T(rng.draw(level, 2 * k) - 0.5);                             // :180
+      T rv = T(rng.draw(level, 2 * k + 1) - 0.5);                         // :181
+      V3<T> lp = add(add(s.a_pos, muls(s.a_u, ru)), muls(s.a_v, rv));     // :182
+      V3<T> ldir = normalize(sub(lp, point));                             // :183
+      V3<T> so = add(point, muls(normal, T(0.001)));                      // :184
+      if (!find_nearest(s, so, ldir, &sh, (double*)nullptr)) {            // :185-187
+        T diffuse = max0(dot(normal, ldir));                              // :188
+        contrib = add(contrib, muls(muls(s.a_col, s.a_int), diffuse));    // :189
+        if (spec_k > 0) {                                                 // :191
+          V3<T> r = sub(ldir, muls(normal, T(2) * dot(ldir, normal)));    // :192
+          T sp = std::pow(max0(dot(view, r)), T(50));                     // :193
+          contrib = add(contrib, muls(muls(muls(s.a_col, s.a_int), spec_k), sp));  // :194
+        }
+      }
+    }
+    color = add(color, muls(contrib, T(1) / T(s.a_samples)));             // :196
+  }
+  return color;                                                           // :211
+}
+
+// trace_ray, raytracer.py:232-260, with the literal depth limit 5 (:233) made a parameter D:
+// `level > D` returns black.  Refraction (:252-254) is out of scope (always 0).
+template <typename T>
+V3<T> trace_ray(const SceneT<T>& s, V3<T> o, V3<T> d, int level, int D, const Rng& rng, PixelStats* st) {
+  if (level > D) return {0, 0, 0};                                        // :233-234
+  st->trace_levels++;
+  Hit<T> h;
+  if (!find_nearest(s, o, d, &h, level == 0 ? &st->margin : nullptr)) {   // :236-238
+    return {0, 0, 0};
+  }
+  if (level == 0) st->primary_hit = h.idx;
+  V3<T> color = s.color[h.idx];                                           // :242
+  T refl = s.reflection[h.idx];
+  if (refl > 0) {                                                         // :245
+    V3<T> rd = sub(d, muls(h.normal, T(2) * dot(d, h.normal)));           // :246
+    V3<T> ro = add(h.point, muls(h.normal, T(0.001)));                    // :247
+    V3<T> rc = trace_ray(s, ro, rd, level + 1, D, rng, st);               // :248
+    color = add(muls(color, T(1) - refl), muls(rc, refl));                // :249
+  }
+  st->hit_levels++;
+  V3<T> light = compute_lighting(s, h.point, h.normal, muls(d, T(-1)), h.idx, rng,
+                                 uint32_t(level + 1));                    // :257
+  return mulv(color, light);                                              // :258
+}
+
+// render_pixel, raytracer.py:289-297 (camera generalised: see raytracer_amd/scene.py Camera)
+template <typename T>
+V3<T> render_pixel(const SceneT<T>& s, int x, int y, int width, int height, int samples, int D,
+                   int mode, uint32_t seed32, PixelStats* st) {
+  T aspect = T(width) / T(height);                                        // :290
+  V3<T> color{0, 0, 0};
+  for (int k = 0; k < samples; ++k) {                                     // :292
+    Rng rng{mode, mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(k))};
+    T u = ((T(x) + T(rng.draw(0, 0))) / T(width)) * T(2) - T(1);          // :293
+    T v = -((T(y) + T(rng.draw(0, 1))) / T(height) * T(2) - T(1)) / aspect;  // :294
+    V3<T> dir = normalize(add(add(muls(s.cam_r, u), muls(s.cam_u, v)), s.cam_f));  // :295
+    st->margin = std::numeric_limits<double>::infinity();
+    st->primary_hit = -1;
+    color = add(color, trace_ray(s, s.cam_o, dir, 0, D, rng, st));        // :296
+  }
+  return muls(color, T(1) / T(samples));                                  // :297
+}
+
+template <typename T>
+void build_scene(SceneT<T>& s, int n, const float* center, const float* radius, const float* color,
+                 const float* specular, const float* reflection, const float* lights,
+                 int area_samples, const float* camera) {
+  s.n = n;
+  s.center.resize(n); s.color.resize(n); s.radius.resize(n); s.specular.resize(n); s.reflection.resize(n);
+  for (int i = 0; i < n; ++i) {
+    s.center[i] = {T(center[3 * i]), T(center[3 * i + 1]), T(center[3 * i + 2])};
+    s.color[i] = {T(color[3 * i]), T(color[3 * i + 1]), T(color[3 * i + 2])};
+    s.radius[i] = T(radius[i]); s.specular[i] = T(specular[i]); s.reflection[i] = T(reflection[i]);
+  }
+  auto v3 = [](const float* p) { return V3<T>{T(p[0]), T(p[1]), T(p[2])}; };
+  s.p_pos = v3(lights); s.p_col = v3(lights + 3); s.p_int = T(lights[6]);
+  s.a_pos = v3(lights + 7); s.a_u = v3(lights + 10); s.a_v = v3(lights + 13);
+  s.a_col = v3(lights + 16); s.a_int = T(lights[19]); s.a_samples = area_samples;
+  s.cam_o = v3(camera); s.cam_r = v3(camera + 3); s.cam_u = v3(camera + 6); s.cam_f = v3(camera + 9);
+}
+
+template <typename T>
+int run(int n, const float* center, const float* radius, const float* color, const float* specular,
+        const float* reflection, const float* lights, int area_samples, const float* camera,
+        int width, int height, const int32_t* pixels, int64_t n_pixels, int samples, int D, int mode,
+        uint64_t seed, int threads, double* out_color, uint8_t* out_rgb8, int32_t* out_hit,
+        int64_t* out_trace_levels, int64_t* out_hit_levels, double* out_margin) {
+  SceneT<T> s;
+  build_scene(s, n, center, radius, color, specular, reflection, lights, area_samples, camera);
+  uint32_t seed32 = uint32_t(seed ^ (seed >> 32));
+  if (!pixels) n_pixels = int64_t(width) * height;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t k = 0; k < n_pixels; ++k) {
+    int x = pixels ? pixels[2 * k] : int(k % width);
+    int y = pixels ? pixels[2 * k + 1] : int(k / width);
+    PixelStats st;
+    V3<T> c = render_pixel(s, x, y, width, height, samples, D, mode, seed32, &st);
+    T ch[3] = {c.x, c.y, c.z};
+    for (int j = 0; j < 3; ++j) {
+      if (out_color) out_color[3 * k + j] = double(ch[j]);
+      T cl = ch[j] < 0 ? T(0) : (ch[j] > 1 ? T(1) : ch[j]);          // render(), :318
+      if (out_rgb8) out_rgb8[3 * k + j] = uint8_t(cl * T(255));       // :325 (truncation)
+    }
+    if (out_hit) out_hit[k] = st.primary_hit;
+    if (out_trace_levels) out_trace_levels[k] = st.trace_levels;
+    if (out_hit_levels) out_hit_levels[k] = st.hit_levels;
+    if (out_margin) out_margin[k] = st.margin;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// precision: 0 = double (the oracle), 1 = float (diagnostic).  pixels = NULL renders the full
+// frame row-major.  Outputs may be NULL.  `hit`/`margin` refer to the LAST sample's primary ray.
+int rto_render_pixels(int n, const float* center, const float* radius, const float* color,
+                      const float* specular, const float* reflection, const float* lights,
+                      int area_samples, const float* camera, int width, int height,
+                      const int32_t* pixels, int64_t n_pixels, int samples, int max_depth, int mode,
+                      uint64_t seed, int precision, int threads, double* out_color,
+                      uint8_t* out_rgb8, int32_t* out_hit, int64_t* out_trace_levels,
+                      int64_t* out_hit_levels, double* out_margin) {
+  if (n < 0 || width <= 0 || height <= 0 || samples <= 0 || area_samples <= 0) return -1;
+  if (precision == 0)
+    return run<double>(n, center, radius, color, specular, reflection, lights, area_samples, camera,
+                       width, height, pixels, n_pixels, samples, max_depth, mode, seed, threads,
+                       out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
+  return run<float>(n, center, radius, color, specular, reflection, lights, area_samples, camera,
+                    width, height, pixels, n_pixels, samples, max_depth, mode, seed, threads,
+                    out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
+}
+
+int rto_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+"""Build librt355.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m raytracer_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the
+tree (it is not in .gpurunignore).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SRC = os.path.join(CSRC, "rt355.hip")
+HDR = os.path.join(os.path.dirname(HERE), "include", "rt355.h")
+SO = os.path.join(CSRC, "librt355.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fno-gpu-sanitize", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build() -> bool:
+    if not os.path.isfile(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(f) > t for f in (SRC, HDR))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", SO, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

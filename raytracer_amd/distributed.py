@@ -1,0 +1,93 @@
+"""Multi-GPU render: interleaved row tiles per rank, one exchange step (gather to rank 0).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank
+renders tiles t = rank, rank+G, ... of the frame with the same keyed RNG, so the assembled image
+is byte-identical to a 1-GPU render.  The only collective is a fixed-size
+``gather`` of the packed uint8 slabs to rank 0 — G-1 concurrent point-to-point transfers, one per
+xGMI link into GPU 0 — followed by a row scatter on the root (rt_scatter_rows).  The reference has
+no distributed code; its unused ``render_chunk`` tile split (raytracer.py:299-308) is the model.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .tiling import DEFAULT_TILE_ROWS, local_rows, max_local_rows
+
+
+def gather_row_tiles(local, width: int, height: int, tile_rows: int, group=None, renderer=None,
+                     dst: int = 0, slab=None, gathered=None, out=None):
+    """Gather every rank's packed rows to ``dst`` and put them in image order.
+
+    ``local``: uint8 tensor [rows_of_this_rank, W, 3] as packed by ``Renderer.render_rows``.
+    Works on GPU tensors (nccl; root placement by the HIP scatter kernel) and on CPU tensors
+    (gloo; root placement by index_copy_ — used by the CPU tests of this exchange step, no pixel
+    is computed here).  Returns the image [H, W, 3] on ``dst`` and None elsewhere.
+    ``slab`` / ``gathered`` / ``out`` let callers reuse buffers across frames.
+    """
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rows_max = max_local_rows(height, tile_rows, world)
+    stride = rows_max * width * 3
+    if slab is None:
+        slab = torch.empty(stride, dtype=torch.uint8, device=local.device)
+    n = local.numel()
+    if n and local.data_ptr() != slab.data_ptr():      # render_rows may have written in place
+        slab[:n].copy_(local.reshape(-1))
+    if world == 1:
+        parts = None
+        gathered = slab.view(1, stride)
+    else:
+        if rank == dst:
+            if gathered is None:
+                gathered = torch.empty((world, stride), dtype=torch.uint8, device=local.device)
+            parts = list(gathered.unbind(0))
+        else:
+            parts = None
+        dist.gather(slab, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    if local.is_cuda:
+        if renderer is None:
+            raise ValueError("a Renderer is required to place GPU tiles (rt_scatter_rows)")
+        return renderer.scatter_rows(gathered, world, width, height, tile_rows, out=out)
+    if out is None:
+        out = torch.empty((height, width, 3), dtype=torch.uint8)
+    for r in range(world):
+        rows = torch.from_numpy(local_rows(height, tile_rows, r, world))
+        out.index_copy_(0, rows, gathered[r, :len(rows) * width * 3].view(len(rows), width, 3))
+    return out
+
+
+def render_distributed(renderer, width, height, samples=1, *, tile_rows=DEFAULT_TILE_ROWS,
+                       group=None, max_depth=5, camera=None, rng_mode="keyed", seed=0,
+                       buffers: dict | None = None):
+    """Render one frame across all ranks of ``group``; rank 0 gets the uint8 [H, W, 3] tensor.
+
+    The scene must already be uploaded on every rank (``renderer.upload_scene``)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    b = buffers if buffers is not None else {}
+    local = renderer.render_rows(width, height, samples, tile_rows=tile_rows, tile_first=rank,
+                                 tile_stride=world, max_depth=max_depth, camera=camera,
+                                 rng_mode=rng_mode, seed=seed, out=b.get("local"))
+    return gather_row_tiles(local, width, height, tile_rows, group=group, renderer=renderer,
+                            slab=b.get("slab"), gathered=b.get("gathered"), out=b.get("out"))
+
+
+def make_buffers(renderer, width, height, tile_rows, world, rank):
+    """Pre-allocate the per-frame buffers used by render_distributed (animation / bench loops)."""
+    import torch
+    dev = f"cuda:{renderer.device}"
+    rows_max = max_local_rows(height, tile_rows, world)
+    slab = torch.empty(rows_max * width * 3, dtype=torch.uint8, device=dev)
+    b = dict(slab=slab, local=slab.view(rows_max, width, 3))   # rows are rendered into the slab
+    if rank == 0:
+        b["gathered"] = torch.empty((world, rows_max * width * 3), dtype=torch.uint8, device=dev)
+        b["out"] = torch.empty((height, width, 3), dtype=torch.uint8, device=dev)
+    return b
+
+
+def frames_of_rank(n_frames: int, rank: int, world: int) -> np.ndarray:
+    """Frame-parallel animation (config 5): frame f -> rank f mod G."""
+    return np.arange(rank, n_frames, world)

@@ -1,0 +1,242 @@
+"""Host side of the rt355 render path: the reference's entry points over the HIP library.
+
+Mirrors ``render(width, height, samples=1)`` (raytracer.py:310-325) and
+``render_chunk(args)`` (raytracer.py:299-308) — same positional arguments, same return
+type/shape/dtype/row order — and reads the module-global :data:`scene` exactly as the reference
+does (raytracer.py:317) unless ``scene=`` is given.  Everything per-pixel happens in
+``csrc/rt355.hip``; PyTorch is used only to own device buffers and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .scenes import Camera, PackedScene, RtCamera, default_scene, pack_scene
+
+#: module-global scene, as in the reference (raytracer.py:78-87); ``render`` reads it at call time
+scene = default_scene()
+
+_DEFAULT_MAX_DEPTH = 5      # the literal in trace_ray (raytracer.py:233)
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("rt355 needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU path")
+    return torch
+
+
+class Renderer:
+    """One GPU context (``rt_ctx``): scene upload once, many renders (animation frames reuse it)."""
+
+    def __init__(self, device: int | None = None):
+        torch = _torch()
+        self._L = _lib.load()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        _lib.check(self._L.rt_create(self.device, ctypes.byref(h)))
+        self._h = h
+        self._packed: PackedScene | None = None
+        self.use_torch_stream()
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        _lib.check(rc, self._h)
+
+    # -- stream / scene -------------------------------------------------------------------
+    def use_torch_stream(self):
+        """Launch on torch's current stream for this device, so torch ops, torch.cuda.Event timing
+        and RCCL collectives order against the render kernels without extra syncs."""
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._L.rt_set_stream(self._h, ctypes.c_void_p(s)))
+
+    def synchronize(self):
+        self._check(self._L.rt_synchronize(self._h))
+
+    def upload_scene(self, scn: dict | PackedScene | None = None) -> PackedScene:
+        p = scn if isinstance(scn, PackedScene) else pack_scene(scene if scn is None else scn)
+        lights = p.ct_lights()
+        g, m, s = (np.ascontiguousarray(a, np.float32) for a in (p.geom4, p.mat4, p.spec))
+        self._check(self._L.rt_upload_scene(self._h, g.ctypes.data, m.ctypes.data, s.ctypes.data,
+                                            p.n_spheres, ctypes.byref(lights)))
+        self._packed = p
+        return p
+
+    # -- renders --------------------------------------------------------------------------
+    def _alloc(self, shape, dtype):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+
+    def render(self, width, height, samples=1, *, max_depth=_DEFAULT_MAX_DEPTH, camera=None,
+               rng_mode="keyed", seed=0, out=None, return_hit_index=False):
+        """Full frame -> uint8 tensor [H, W, 3] on the GPU (and int32 [H, W] hit index)."""
+        torch = _torch()
+        width, height = _dims(width, height)
+        if out is None:
+            out = self._alloc((height, width, 3), torch.uint8)
+        _check_out(out, (height, width, 3), torch.uint8, self.device)
+        hit = self._alloc((height, width), torch.int32) if return_hit_index else None
+        cam = RtCamera.from_camera(camera)
+        if width * height:
+            self._check(self._L.rt_render(self._h, ctypes.byref(cam), width, height, int(samples),
+                                          int(max_depth), _lib.RNG_MODES[rng_mode], int(seed),
+                                          out.data_ptr(), hit.data_ptr() if hit is not None else None))
+        return (out, hit) if return_hit_index else out
+
+    def render_rows(self, width, height, samples=1, *, tile_rows, tile_first, tile_stride,
+                    max_depth=_DEFAULT_MAX_DEPTH, camera=None, rng_mode="keyed", seed=0, out=None):
+        """Row tiles tile_first, tile_first+tile_stride, ... packed -> uint8 [rows, W, 3]."""
+        torch = _torch()
+        from .tiling import local_row_count
+        width, height = _dims(width, height)
+        rows = local_row_count(height, tile_rows, tile_first, tile_stride)
+        if out is None:
+            out = self._alloc((rows, width, 3), torch.uint8)
+        if out.shape[0] < rows:
+            raise ValueError(f"out holds {out.shape[0]} rows, {rows} needed")
+        _check_out(out, (out.shape[0], width, 3), torch.uint8, self.device)
+        cam = RtCamera.from_camera(camera)
+        n = ctypes.c_int(0)
+        self._check(self._L.rt_render_rows(self._h, ctypes.byref(cam), width, height, int(samples),
+                                           int(max_depth), _lib.RNG_MODES[rng_mode], int(seed),
+                                           int(tile_rows), int(tile_first), int(tile_stride),
+                                           out.data_ptr(), None, ctypes.byref(n)))
+        assert n.value == rows, (n.value, rows)
+        return out[:rows]
+
+    def render_chunk(self, x_start, x_end, y_start, y_end, width, height, samples=1, *,
+                     max_depth=_DEFAULT_MAX_DEPTH, camera=None, rng_mode="keyed", seed=0):
+        """Clamped float32 colour of a sub-rectangle -> tensor [y_end-y_start, x_end-x_start, 3]."""
+        torch = _torch()
+        h, w = int(y_end) - int(y_start), int(x_end) - int(x_start)
+        if h < 0 or w < 0:
+            raise ValueError("negative dimensions are not allowed")   # numpy's message (np.zeros)
+        out = self._alloc((h, w, 3), torch.float32)
+        cam = RtCamera.from_camera(camera)
+        if h * w:
+            self._check(self._L.rt_render_chunk(self._h, ctypes.byref(cam), int(x_start), int(x_end),
+                                                int(y_start), int(y_end), int(width), int(height),
+                                                int(samples), int(max_depth),
+                                                _lib.RNG_MODES[rng_mode], int(seed), out.data_ptr()))
+        return out
+
+    def render_frames(self, cameras, seeds, width, height, samples=1, *,
+                      max_depth=_DEFAULT_MAX_DEPTH, rng_mode="keyed", out=None):
+        """Animation batch -> uint8 [F, H, W, 3]."""
+        torch = _torch()
+        width, height = _dims(width, height)
+        n = len(cameras)
+        if len(seeds) != n:
+            raise ValueError("one seed per camera")
+        if out is None:
+            out = self._alloc((n, height, width, 3), torch.uint8)
+        _check_out(out, (n, height, width, 3), torch.uint8, self.device)
+        cams = (RtCamera * max(n, 1))(*[RtCamera.from_camera(c) for c in cameras])
+        sd = (ctypes.c_uint64 * max(n, 1))(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds])
+        if n and width * height:
+            self._check(self._L.rt_render_frames(self._h, cams, sd, n, width, height, int(samples),
+                                                 int(max_depth), _lib.RNG_MODES[rng_mode],
+                                                 out.data_ptr()))
+        return out
+
+    def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
+        """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
+        torch = _torch()
+        if out is None:
+            out = self._alloc((height, width, 3), torch.uint8)
+        g = gathered
+        if g.dim() != 2 or g.shape[0] != n_ranks or g.dtype != torch.uint8 or g.stride(1) != 1:
+            raise ValueError("gathered must be a uint8 [n_ranks, slab_bytes] tensor with unit inner stride")
+        _check_out(out, (height, width, 3), torch.uint8, self.device)
+        self._check(self._L.rt_scatter_rows(self._h, g.data_ptr(), g.stride(0) if n_ranks > 1 else g.shape[1],
+                                            n_ranks, width, height, tile_rows, out.data_ptr()))
+        return out
+
+    def ray_counts(self) -> dict:
+        """{'primary','reflection','shadow','shaded_hits','total'} since the last reset (syncs)."""
+        a = (ctypes.c_uint64 * 4)()
+        self._check(self._L.rt_get_ray_counts(self._h, a))
+        d = dict(primary=a[0], reflection=a[1], shadow=a[2], shaded_hits=a[3])
+        d["total"] = a[0] + a[1] + a[2]
+        return d
+
+    def reset_ray_counts(self):
+        self._check(self._L.rt_reset_ray_counts(self._h))
+
+
+def _dims(width, height):
+    width, height = int(width), int(height)
+    if width < 0 or height < 0:
+        raise ValueError("negative dimensions are not allowed")       # np.zeros((h, w, 3)), :314
+    return width, height
+
+
+def _check_out(t, shape, dtype, device):
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous() \
+            or not t.is_cuda or t.device.index != device:
+        raise ValueError(f"out must be a contiguous {dtype} tensor of shape {shape} on cuda:{device}")
+
+
+_renderers: dict = {}
+
+
+def _renderer(device=None) -> Renderer:
+    torch = _torch()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    r = _renderers.get(dev)
+    if r is None:
+        r = _renderers[dev] = Renderer(dev)
+    r.use_torch_stream()
+    return r
+
+
+def render(width, height, samples=1, *, scene=None, max_depth=_DEFAULT_MAX_DEPTH, camera=None,
+           rng_mode="keyed", seed=0, device=None, return_hit_index=False):
+    """Drop-in for the reference's ``render(width, height, samples=1)`` (raytracer.py:310-325).
+
+    Returns ``np.ndarray[uint8, (height, width, 3)]``, row 0 = top, ready for
+    ``glTexImage2D(..., GL_RGB, GL_UNSIGNED_BYTE, image)`` (raytracer.py:346) or PIL.
+    ``scene=None`` reads this module's global ``scene`` (as raytracer.py:317 does); the
+    keyword-only extensions default to the reference's literals (max_depth 5, fixed pinhole).
+    ``rng_mode``: the reference draws jitter / area-light samples from Python's unseeded global
+    Mersenne Twister, so any stream is "the reference's"; ``"keyed"`` (default) is a per-pixel hash
+    stream reproducible across GPU counts, ``"constant"`` fixes every draw at 0.5.
+    """
+    r = _renderer(device)
+    r.upload_scene(globals()["scene"] if scene is None else scene)
+    res = r.render(width, height, samples, max_depth=max_depth, camera=camera, rng_mode=rng_mode,
+                   seed=seed, return_hit_index=return_hit_index)
+    if return_hit_index:
+        return res[0].cpu().numpy(), res[1].cpu().numpy()
+    return res.cpu().numpy()
+
+
+def render_chunk(args, *, max_depth=_DEFAULT_MAX_DEPTH, camera=None, rng_mode="keyed", seed=0,
+                 device=None):
+    """Drop-in for ``render_chunk(args)`` (raytracer.py:299-308): ``args`` is the reference's tuple
+    ``(x_start, x_end, y_start, y_end, width, height, scene, samples)``; returns the clamped,
+    unquantised colour as ``np.ndarray[float64, (y_end-y_start, x_end-x_start, 3)]`` (computed in
+    float32 on the GPU)."""
+    x_start, x_end, y_start, y_end, width, height, scn, samples = args
+    r = _renderer(device)
+    r.upload_scene(scn)
+    t = r.render_chunk(x_start, x_end, y_start, y_end, width, height, samples, max_depth=max_depth,
+                       camera=camera, rng_mode=rng_mode, seed=seed)
+    return t.cpu().numpy().astype(np.float64)

@@ -1,0 +1,296 @@
+"""Scene description for the rt355 render path.
+
+Host-side mirror of the reference's scene types (``/root/reference/raytracer.py:10-87``):
+``Vector3``, ``Material``, ``Sphere``, ``Light``, ``AreaLight`` and the module-global ``scene``
+dict with keys ``spheres`` / ``global_light`` / ``area_light``.  Attribute names are the
+reference's, so a scene dict built for the reference can be handed to :func:`pack_scene`
+unchanged (duck-typed: anything exposing ``.x/.y/.z`` etc. works).
+
+The device layout is struct-of-arrays:
+
+* ``geom4[N,4]`` = ``cx, cy, cz, r*r``     (float32, 16 B per sphere, staged into LDS)
+* ``mat4[N,4]``  = ``R, G, B, reflection`` (float32)
+* ``spec[N]``    = ``specular``            (float32)
+
+plus one ``rt_lights`` block (point light + area light) and one ``rt_camera`` block.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+__all__ = [
+    "Vector3", "Material", "Sphere", "Light", "AreaLight", "Camera",
+    "default_scene", "generate_scene", "pack_scene", "scene_from_arrays",
+    "orbit_camera", "PackedScene", "RtLights", "RtCamera",
+    "MAX_SPHERES", "MAX_AREA_SAMPLES",
+]
+
+MAX_SPHERES = 4096        # rt355.h RT_MAX_SPHERES (LDS: 16 B geometry per sphere)
+MAX_AREA_SAMPLES = 64     # rt355.h RT_MAX_AREA_SAMPLES
+
+
+@dataclass
+class Vector3:
+    """3-vector with the reference's field names (raytracer.py:10-14). Only data here:
+    the arithmetic lives in the HIP kernel (float3 register math)."""
+    x: float
+    y: float
+    z: float
+
+    def as_tuple(self):
+        return (float(self.x), float(self.y), float(self.z))
+
+
+@dataclass
+class Material:
+    """raytracer.py:42-48. ``refraction``/``refractive_index`` are carried but must be 0/unused:
+    the refraction branch (raytracer.py:213-230, 252-254) is out of scope."""
+    color: Vector3
+    specular: float = 0
+    reflection: float = 0
+    refraction: float = 0
+    refractive_index: float = 1
+
+
+@dataclass
+class Sphere:
+    """raytracer.py:50-54."""
+    center: Vector3
+    radius: float
+    material: Material
+
+
+@dataclass
+class Light:
+    """Point light, raytracer.py:62-66."""
+    position: Vector3
+    color: Vector3
+    intensity: float
+
+
+@dataclass
+class AreaLight:
+    """Parallelogram light, raytracer.py:68-75 (``samples`` defaults to 4 as in the reference)."""
+    position: Vector3
+    u: Vector3
+    v: Vector3
+    color: Vector3
+    intensity: float
+    samples: int = 4
+
+
+@dataclass
+class Camera:
+    """Pinhole camera. The reference has none: its primary ray is
+    ``Ray((0,0,0), normalize((u, v, -1)))`` (raytracer.py:295). This struct generalises that to
+    ``origin + normalize(right*u + up*v + forward)`` and reduces to the reference exactly for
+    the default values (multiplying by 1.0 / adding 0.0 is exact)."""
+    origin: tuple = (0.0, 0.0, 0.0)
+    right: tuple = (1.0, 0.0, 0.0)
+    up: tuple = (0.0, 1.0, 0.0)
+    forward: tuple = (0.0, 0.0, -1.0)
+
+    def as_array(self) -> np.ndarray:
+        a = np.array([self.origin, self.right, self.up, self.forward], dtype=np.float32)
+        if a.shape != (4, 3) or not np.all(np.isfinite(a)):
+            raise ValueError("camera must be four finite 3-vectors")
+        return a
+
+
+def default_scene() -> dict:
+    """The reference's shipped scene, raytracer.py:78-87 (values restated, not imported)."""
+    return {
+        "global_light": Light(Vector3(0, 10, 10), Vector3(1, 1, 1), 0.9),
+        "area_light": AreaLight(Vector3(5, 5, 5), Vector3(1, 0, 0), Vector3(0, 1, 0),
+                                Vector3(1, 1, 1), 0.9, samples=12),
+        "spheres": [
+            Sphere(Vector3(0, 0, -5), 1,
+                   Material(Vector3(1, 0.59, 0.35), specular=1.0, reflection=0.4)),
+            Sphere(Vector3(-2.5, 0, -7), 1.5,
+                   Material(Vector3(0.35, 1, 0.63), specular=1.0, reflection=0.6)),
+            Sphere(Vector3(2.5, 0, -6), 0.75,
+                   Material(Vector3(0.35, 1, 1), specular=1.0, reflection=0.7)),
+        ],
+    }
+
+
+# --------------------------------------------------------------------------------------
+# ctypes mirrors of include/rt355.h
+# --------------------------------------------------------------------------------------
+class RtCamera(ctypes.Structure):
+    _fields_ = [("origin", ctypes.c_float * 3), ("right", ctypes.c_float * 3),
+                ("up", ctypes.c_float * 3), ("forward", ctypes.c_float * 3)]
+
+    @classmethod
+    def from_camera(cls, cam: "Camera | None") -> "RtCamera":
+        a = (cam or Camera()).as_array()
+        out = cls()
+        for i, name in enumerate(("origin", "right", "up", "forward")):
+            getattr(out, name)[:] = [float(v) for v in a[i]]
+        return out
+
+
+class RtLights(ctypes.Structure):
+    _fields_ = [("point_pos", ctypes.c_float * 3), ("point_color", ctypes.c_float * 3),
+                ("point_intensity", ctypes.c_float),
+                ("area_pos", ctypes.c_float * 3), ("area_u", ctypes.c_float * 3),
+                ("area_v", ctypes.c_float * 3), ("area_color", ctypes.c_float * 3),
+                ("area_intensity", ctypes.c_float), ("area_samples", ctypes.c_int32)]
+
+
+@dataclass
+class PackedScene:
+    geom4: np.ndarray        # [N,4] float32: cx cy cz r^2
+    mat4: np.ndarray         # [N,4] float32: R G B reflection
+    spec: np.ndarray         # [N]   float32
+    radius: np.ndarray       # [N]   float32 (kept for round-tripping to objects)
+    lights: np.ndarray       # [20]  float32: ppos3 pcol3 pint | apos3 au3 av3 acol3 aint
+    area_samples: int
+    _ct: RtLights = field(default=None, repr=False)
+
+    @property
+    def n_spheres(self) -> int:
+        return int(self.geom4.shape[0])
+
+    def ct_lights(self) -> RtLights:
+        L = RtLights()
+        v = [float(x) for x in self.lights]
+        L.point_pos[:] = v[0:3]; L.point_color[:] = v[3:6]; L.point_intensity = v[6]
+        L.area_pos[:] = v[7:10]; L.area_u[:] = v[10:13]; L.area_v[:] = v[13:16]
+        L.area_color[:] = v[16:19]; L.area_intensity = v[19]
+        L.area_samples = int(self.area_samples)
+        return L
+
+
+def _v3(v) -> tuple:
+    return (float(v.x), float(v.y), float(v.z))
+
+
+def pack_scene(scene: dict) -> PackedScene:
+    """Flatten a reference-style scene dict into the SoA device layout.
+
+    Values are rounded to float32 here, once; ``r*r`` is formed in float32 from the float32
+    radius so the kernel sees exactly what :func:`scene_from_arrays` hands the FP64 oracle.
+    Errors mirror what the reference would hit: a missing key raises ``KeyError``
+    (raytracer.py:156,176); non-sphere objects and refractive materials are rejected because
+    the cube / refraction branches are out of scope.
+    """
+    spheres = scene["spheres"]
+    n = len(spheres)
+    if n > MAX_SPHERES:
+        raise ValueError(f"scene has {n} spheres; this build supports at most {MAX_SPHERES}")
+    geom = np.zeros((n, 4), np.float32)
+    mat = np.zeros((n, 4), np.float32)
+    spec = np.zeros((n,), np.float32)
+    rad = np.zeros((n,), np.float32)
+    for i, s in enumerate(spheres):
+        if not (hasattr(s, "center") and hasattr(s, "radius")):
+            raise TypeError(f"scene['spheres'][{i}] is not a sphere (cubes are out of scope)")
+        m = s.material
+        if float(getattr(m, "refraction", 0)) > 0:
+            raise NotImplementedError("material.refraction > 0 is out of scope for the HIP path")
+        r32 = np.float32(s.radius)
+        geom[i, :3] = _v3(s.center)
+        geom[i, 3] = r32 * r32
+        mat[i, :3] = _v3(m.color)
+        mat[i, 3] = m.reflection
+        spec[i] = m.specular
+        rad[i] = r32
+    pl, al = scene["global_light"], scene["area_light"]
+    ns = int(al.samples)
+    if not (1 <= ns <= MAX_AREA_SAMPLES):
+        raise ValueError(f"area_light.samples must be in [1, {MAX_AREA_SAMPLES}], got {ns}")
+    lights = np.array([*_v3(pl.position), *_v3(pl.color), float(pl.intensity),
+                       *_v3(al.position), *_v3(al.u), *_v3(al.v), *_v3(al.color),
+                       float(al.intensity)], dtype=np.float32)
+    for name, a in (("geom4", geom), ("mat4", mat), ("spec", spec), ("lights", lights)):
+        if not np.all(np.isfinite(a)):
+            raise ValueError(f"scene has non-finite values in {name}")
+    return PackedScene(geom, mat, spec, rad, lights, ns)
+
+
+def scene_from_arrays(center, radius, color, specular, reflection, lights=None,
+                      area_samples=12) -> dict:
+    """Build a reference-style scene dict from arrays (float32 values widened to Python floats),
+    so oracle and kernel see bit-identical inputs."""
+    center = np.asarray(center, np.float32); radius = np.asarray(radius, np.float32)
+    color = np.asarray(color, np.float32)
+    specular = np.asarray(specular, np.float32); reflection = np.asarray(reflection, np.float32)
+    sph = [Sphere(Vector3(*map(float, center[i])), float(radius[i]),
+                  Material(Vector3(*map(float, color[i])), specular=float(specular[i]),
+                           reflection=float(reflection[i])))
+           for i in range(len(radius))]
+    d = default_scene()
+    if lights is not None:
+        v = [float(x) for x in np.asarray(lights, np.float32)]
+        d["global_light"] = Light(Vector3(*v[0:3]), Vector3(*v[3:6]), v[6])
+        d["area_light"] = AreaLight(Vector3(*v[7:10]), Vector3(*v[10:13]), Vector3(*v[13:16]),
+                                    Vector3(*v[16:19]), v[19], samples=int(area_samples))
+    d["spheres"] = sph
+    return d
+
+
+def generate_scene(n_spheres: int, seed: int, width: int = 1920, height: int = 1080,
+                   keep_default: bool = False) -> dict:
+    """Deterministic synthetic scenes for BASELINE.json configs 2-5.
+
+    ``numpy.random.default_rng(seed)`` (PCG64); centre inside the view frustum
+    (``z ~ U(-24,-4)``, ``x ~ U(-1,1)*|z|*0.9``, ``y ~ U(-1,1)*|z|*0.9*H/W``); radius
+    ``U(0.3,1.2)*(8/N)^(1/3)`` clipped to >= 0.08; colour ``U(0.2,1)^3``; specular 1;
+    reflection ``U(0.2,0.8)``; spheres overlapping an accepted sphere, the camera origin or a
+    light are rejected.  ``keep_default`` starts from the reference's three spheres (config 2:
+    default 3 + 5 generated).  Every value is rounded to float32.  Lights are the reference's.
+    """
+    rng = np.random.default_rng(seed)
+    base = default_scene()
+    centers, radii, colors, refl = [], [], [], []
+    if keep_default:
+        for s in base["spheres"]:
+            centers.append(np.array(_v3(s.center))); radii.append(float(s.radius))
+            colors.append(np.array(_v3(s.material.color))); refl.append(float(s.material.reflection))
+    keep = [np.zeros(3), np.array(_v3(base["global_light"].position)),
+            np.array(_v3(base["area_light"].position))]
+    scale = (8.0 / max(n_spheres, 1)) ** (1.0 / 3.0)
+    tries = 0
+    while len(radii) < n_spheres:
+        tries += 1
+        if tries > 2_000_000:
+            raise RuntimeError("scene generator could not place all spheres")
+        z = rng.uniform(-24.0, -4.0)
+        x = rng.uniform(-1.0, 1.0) * abs(z) * 0.9
+        y = rng.uniform(-1.0, 1.0) * abs(z) * 0.9 * height / width
+        r = max(0.08, rng.uniform(0.3, 1.2) * scale)
+        col = rng.uniform(0.2, 1.0, 3)
+        rf = rng.uniform(0.2, 0.8)
+        c = np.array([x, y, z])
+        if any(np.linalg.norm(c - k) <= r * 1.05 for k in keep):
+            continue
+        if centers:
+            d = np.linalg.norm(np.array(centers) - c, axis=1)
+            if np.any(d <= (np.array(radii) + r) * 1.02):
+                continue
+        centers.append(c); radii.append(r); colors.append(col); refl.append(rf)
+    lights = pack_scene(base).lights
+    return scene_from_arrays(np.array(centers), np.array(radii), np.array(colors),
+                             np.ones(len(radii)), np.array(refl), lights, 12)
+
+
+def orbit_camera(frame: int, n_frames: int = 256, radius: float = 6.0,
+                 center=(0.0, 0.0, -6.0), height: float = 1.0) -> Camera:
+    """Config 5: camera on a circle of ``radius`` around ``center`` at
+    ``height``, looking at the centre; frame f at angle 2*pi*f/n_frames. Frame 0 sits at
+    +z of the centre, i.e. near the reference's fixed camera position."""
+    ang = 2.0 * math.pi * frame / n_frames
+    c = np.array(center, np.float64)
+    o = c + np.array([radius * math.sin(ang), height, radius * math.cos(ang)])
+    f = c - o
+    f /= np.linalg.norm(f)
+    r = np.cross(f, np.array([0.0, 1.0, 0.0]))
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    return Camera(tuple(np.float32(o).tolist()), tuple(np.float32(r).tolist()),
+                  tuple(np.float32(u).tolist()), tuple(np.float32(f).tolist()))

@@ -1,0 +1,59 @@
+"""The N>1 exchange step on CPU: world_size-2 (and 3) gloo runs of gather_row_tiles.  Each rank's
+rows come from the oracle here (no GPU in this container); on the GPU box the same function moves
+rt_render_rows output over RCCL (tests/test_gpu_properties.py covers tile == full-frame)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, tile_rows, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cpu_oracle
+        from raytracer_amd import tiling
+        from raytracer_amd.distributed import frames_of_rank, gather_row_tiles
+        from raytracer_amd.scenes import default_scene
+        rows = tiling.local_rows(h, tile_rows, rank, world)
+        px = np.stack([np.tile(np.arange(w), len(rows)), np.repeat(rows, w)], 1)
+        o = cpu_oracle.render_scene(default_scene(), w, h, pixels=px, max_depth=3, mode="K", seed=4, threads=2)
+        local = torch.from_numpy(o["rgb8"].reshape(len(rows), w, 3))
+        img = gather_row_tiles(local, w, h, tile_rows)
+        if rank == 0:
+            full = cpu_oracle.render_scene(default_scene(), w, h, max_depth=3, mode="K", seed=4, threads=2)
+            ok = np.array_equal(img.numpy(), full["rgb8"].reshape(h, w, 3))
+            fr = [frames_of_rank(10, r, world).tolist() for r in range(world)]
+            q.put((ok, bool(img.numpy().any()), sorted(sum(fr, [])) == list(range(10))))
+        else:
+            assert img is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,tile_rows", [(2, 64, 48, 8), (3, 40, 37, 8), (2, 16, 5, 8)])
+def test_gather_row_tiles_gloo(world, w, h, tile_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, tile_rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ok, nonblack, frames_ok = q.get(timeout=5)
+    assert ok and frames_ok and (nonblack or h < 8)

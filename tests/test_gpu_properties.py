@@ -1,0 +1,140 @@
+"""Size-independent properties of the HIP path at BASELINE's full sizes, API mirror behaviour and
+error handling (all through the C ABI)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import raytracer_amd
+from raytracer_amd import _lib, tiling
+from raytracer_amd.scenes import RtCamera, default_scene, generate_scene, orbit_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def test_row_tiles_reassemble_byte_identical(renderer):
+    """Config 4's sharding on one GPU: render each rank's tiles separately, scatter, compare."""
+    import torch
+    scene = generate_scene(64, 2)
+    renderer.upload_scene(scene)
+    for (w, h, tr, G) in ((1920, 1080, 8, 2), (1920, 1080, 8, 8), (3840, 2160, 16, 4), (333, 187, 8, 3)):
+        full = renderer.render(w, h, 1, max_depth=5, seed=5)
+        rows_max = tiling.max_local_rows(h, tr, G)
+        gathered = torch.zeros((G, rows_max * w * 3), dtype=torch.uint8, device="cuda:0")
+        for r in range(G):
+            loc = renderer.render_rows(w, h, 1, tile_rows=tr, tile_first=r, tile_stride=G, max_depth=5, seed=5)
+            assert loc.shape[0] == tiling.local_row_count(h, tr, r, G)
+            gathered[r, :loc.numel()] = loc.reshape(-1)
+            rows = torch.from_numpy(tiling.local_rows(h, tr, r, G)).cuda()
+            assert torch.equal(loc, full[rows])
+        img = renderer.scatter_rows(gathered, G, w, h, tr)
+        assert torch.equal(img, full)
+
+
+def test_deterministic_and_seed_sensitive(renderer):
+    import torch
+    renderer.upload_scene(generate_scene(8, 1, keep_default=True))
+    a = renderer.render(1920, 1080, 1, seed=1)
+    b = renderer.render(1920, 1080, 1, seed=1)
+    c = renderer.render(1920, 1080, 1, seed=2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_mode_c_is_independent_of_sample_count(renderer):
+    """In mode C every sample is the same ray, and (k*c)*(1/k) is exact for k a power of two."""
+    import torch
+    renderer.upload_scene(default_scene())
+    a = renderer.render(640, 480, 1, rng_mode="C")
+    b = renderer.render(640, 480, 4, rng_mode="C")
+    assert torch.equal(a, b)
+
+
+def test_chunk_matches_frame(renderer):
+    """render_chunk tiles quantise to the same bytes as render (raytracer.py:305 vs :318,:325)."""
+    renderer.upload_scene(generate_scene(8, 1, keep_default=True))
+    full = renderer.render(1920, 1080, 1, seed=9).cpu().numpy()
+    for (x0, x1, y0, y1) in ((0, 1920, 0, 1080), (100, 421, 333, 400), (1900, 1920, 1070, 1080), (5, 6, 7, 8)):
+        c = renderer.render_chunk(x0, x1, y0, y1, 1920, 1080, 1, seed=9).cpu().numpy()
+        assert c.min() >= 0 and c.max() <= 1
+        assert np.array_equal((c * np.float32(255)).astype(np.uint8), full[y0:y1, x0:x1])
+
+
+def test_frames_batch_equals_single_renders(renderer):
+    import torch
+    renderer.upload_scene(generate_scene(8, 1, keep_default=True))
+    cams = [orbit_camera(f) for f in (0, 3, 77)]
+    batch = renderer.render_frames(cams, [0, 3, 77], 640, 360, 1)
+    for i, f in enumerate((0, 3, 77)):
+        assert torch.equal(batch[i], renderer.render(640, 360, 1, camera=cams[i], seed=f))
+
+
+def test_8k_frame_runs_and_counts(renderer):
+    """Config 4 full size on one GPU: finishes, is not black, counters obey the closed form."""
+    renderer.upload_scene(generate_scene(1024, 3, 7680, 4320))
+    renderer.reset_ray_counts()
+    img = renderer.render(7680, 4320, 1, max_depth=5, seed=0)
+    rc = renderer.ray_counts()
+    assert rc["primary"] == 7680 * 4320 and rc["shadow"] == 13 * rc["shaded_hits"]
+    assert rc["shaded_hits"] > 0.2 * rc["primary"]
+    assert int(img.max()) > 100
+
+
+def test_module_level_render_mirrors_reference_api(renderer):
+    """render(width, height, samples) -> uint8 [H,W,3], reading the module-global scene."""
+    img = raytracer_amd.render(64, 48)
+    assert isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.shape == (48, 64, 3)
+    assert img.any()
+    img2, hit = raytracer_amd.render(64, 48, 1, return_hit_index=True)
+    assert np.array_equal(img, img2) and hit.shape == (48, 64) and hit.max() <= 2
+    saved = raytracer_amd.scene
+    try:
+        s = default_scene(); s["spheres"] = []
+        raytracer_amd.set_scene(s)
+        assert not raytracer_amd.render(16, 8).any()
+    finally:
+        raytracer_amd.set_scene(saved)
+    ch = raytracer_amd.render_chunk((8, 24, 4, 20, 64, 48, default_scene(), 1))
+    assert ch.dtype == np.float64 and ch.shape == (16, 16, 3)
+    assert np.array_equal((ch.astype(np.float32) * np.float32(255)).astype(np.uint8), img[4:20, 8:24])
+    assert raytracer_amd.render(0, 0).shape == (0, 0, 3)
+    with pytest.raises(ValueError):
+        raytracer_amd.render(-1, 4)
+
+
+def test_abi_error_paths():
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.rt_create(0, ctypes.byref(h)) == 0
+    try:
+        cam = RtCamera.from_camera(None)
+        import torch
+        buf = torch.empty(16 * 16 * 3, dtype=torch.uint8, device="cuda:0")
+        # render before upload
+        assert L.rt_render(h, ctypes.byref(cam), 16, 16, 1, 5, 1, 0, buf.data_ptr(), None) == -3
+        assert b"rt_upload_scene" in L.rt_last_error(h)
+        r = raytracer_amd.Renderer(0)
+        p = r.upload_scene(default_scene())
+        lights = p.ct_lights()
+        g = np.ascontiguousarray(p.geom4); m = np.ascontiguousarray(p.mat4); s = np.ascontiguousarray(p.spec)
+        up = lambda n, L_=lights, g_=g: L.rt_upload_scene(h, g_.ctypes.data, m.ctypes.data, s.ctypes.data, n, ctypes.byref(L_))
+        assert up(3) == 0
+        assert up(-1) == -1 and up(5000) == -1
+        bad = np.array(g); bad[0, 0] = np.nan
+        assert up(3, lights, bad) == -1 and b"non-finite" in L.rt_last_error(h)
+        bl = p.ct_lights(); bl.area_samples = 0
+        assert up(3, bl) == -1
+        assert up(3) == 0
+        for args in ((0, 16, 1, 5, 1), (16, 16, 0, 5, 1), (16, 16, 1, -1, 1), (16, 16, 1, 65, 1), (16, 16, 1, 5, 7)):
+            w, hh, spp, D, mode = args
+            assert L.rt_render(h, ctypes.byref(cam), w, hh, spp, D, mode, 0, buf.data_ptr(), None) == -1, args
+        assert L.rt_render(h, ctypes.byref(cam), 16, 16, 1, 5, 1, 0, None, None) == -1
+        assert L.rt_render(h, None, 16, 16, 1, 5, 1, 0, buf.data_ptr(), None) == -1
+        n = ctypes.c_int(-1)
+        assert L.rt_render_rows(h, ctypes.byref(cam), 16, 16, 1, 5, 1, 0, 8, 2, 2, buf.data_ptr(), None, ctypes.byref(n)) == -1
+        assert L.rt_render_rows(h, ctypes.byref(cam), 16, 16, 1, 5, 1, 0, 8, 3, 4, buf.data_ptr(), None, ctypes.byref(n)) == 0
+        assert n.value == 0                                  # rank 3 of 4 owns no tile of a 16-row frame
+        assert L.rt_render(h, ctypes.byref(cam), 16, 16, 1, 5, 1, 0, buf.data_ptr(), None) == 0
+        assert L.rt_synchronize(h) == 0
+        r.close()
+    finally:
+        L.rt_destroy(h)

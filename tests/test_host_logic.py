@@ -1,0 +1,124 @@
+"""Host-side logic that needs no GPU: scene packing, generators, tiling, ABI surface."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raytracer_amd import _lib, tiling
+from raytracer_amd.scenes import (Camera, RtCamera, RtLights, default_scene, generate_scene,
+                                  orbit_camera, pack_scene, scene_from_arrays)
+
+
+def test_pack_default_scene_layout():
+    p = pack_scene(default_scene())
+    assert p.geom4.shape == (3, 4) and p.mat4.shape == (3, 4) and p.spec.shape == (3,)
+    assert p.geom4.dtype == np.float32
+    assert np.allclose(p.geom4[1], [-2.5, 0, -7, 2.25])           # cx cy cz r^2
+    assert np.allclose(p.mat4[2], [0.35, 1, 1, 0.7])              # R G B reflection
+    assert p.area_samples == 12 and np.allclose(p.lights[:7], [0, 10, 10, 1, 1, 1, 0.9])
+    L = p.ct_lights()
+    assert L.area_samples == 12 and abs(L.area_intensity - 0.9) < 1e-6 and L.area_pos[0] == 5.0
+
+
+def test_scene_roundtrip_is_float32_exact():
+    p = pack_scene(generate_scene(16, 5))
+    s2 = scene_from_arrays(p.geom4[:, :3], p.radius, p.mat4[:, :3], p.spec, p.mat4[:, 3], p.lights, 12)
+    p2 = pack_scene(s2)
+    for a, b in ((p.geom4, p2.geom4), (p.mat4, p2.mat4), (p.spec, p2.spec), (p.lights, p2.lights)):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n,seed,keep", [(8, 1, True), (64, 2, False), (1024, 3, False)])
+def test_generated_scenes(n, seed, keep):
+    a = pack_scene(generate_scene(n, seed, keep_default=keep))
+    b = pack_scene(generate_scene(n, seed, keep_default=keep))
+    assert a.n_spheres == n and np.array_equal(a.geom4, b.geom4)            # deterministic
+    c, r = a.geom4[:, :3].astype(np.float64), a.radius.astype(np.float64)
+    d = np.linalg.norm(c[:, None] - c[None], axis=-1) + np.eye(n) * 1e9
+    assert (d > r[:, None] + r[None]).all()                                   # no overlaps
+    assert (np.linalg.norm(c, axis=1) > r).all()                              # camera outside
+    assert (a.mat4[:, 3] >= 0.2).all() and (a.mat4[:, 3] <= 0.8).all()
+    if keep:
+        assert np.array_equal(a.geom4[:3], pack_scene(default_scene()).geom4)
+
+
+def test_limits_are_enforced():
+    s = default_scene()
+    s["area_light"].samples = 0
+    with pytest.raises(ValueError):
+        pack_scene(s)
+    s["area_light"].samples = 65
+    with pytest.raises(ValueError):
+        pack_scene(s)
+
+
+def test_orbit_camera_is_orthonormal_and_looks_at_centre():
+    for f in (0, 1, 64, 200, 255):
+        a = orbit_camera(f).as_array().astype(np.float64)
+        o, r, u, fw = a
+        assert abs(np.linalg.norm(r) - 1) < 1e-6 and abs(np.linalg.norm(fw) - 1) < 1e-6
+        assert abs(r @ u) < 1e-6 and abs(r @ fw) < 1e-6 and abs(u @ fw) < 1e-6
+        to_c = np.array([0, 0, -6.0]) - o
+        assert np.allclose(to_c / np.linalg.norm(to_c), fw, atol=1e-6)
+    d = Camera().as_array()
+    assert np.array_equal(d, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, -1]])
+
+
+@pytest.mark.parametrize("height,tile_rows,world", [(1080, 8, 1), (1080, 8, 2), (1080, 8, 8),
+                                                     (4320, 16, 4), (37, 8, 3), (5, 8, 4), (1, 1, 2)])
+def test_row_tiles_partition_the_image(height, tile_rows, world):
+    seen = np.concatenate([tiling.local_rows(height, tile_rows, r, world) for r in range(world)])
+    assert np.array_equal(np.sort(seen), np.arange(height))                   # each row exactly once
+    counts = [tiling.local_row_count(height, tile_rows, r, world) for r in range(world)]
+    assert max(counts) == tiling.max_local_rows(height, tile_rows, world)
+    assert max(counts) - min(counts) <= tile_rows                             # balanced
+
+
+def test_ctypes_structs_match_header():
+    assert ctypes.sizeof(RtCamera) == 48
+    assert ctypes.sizeof(RtLights) == 84
+    hdr = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    assert "float origin[3];" in hdr and "int32_t area_samples;" in hdr
+
+
+def test_shared_library_exports_every_declared_symbol():
+    """include/rt355.h <-> librt355.so <-> the ctypes table agree (no compute call: no GPU here)."""
+    hdr = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    L = _lib.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.library_path()], text=True)
+    exported = set(re.findall(r" T (rt_[a-z_]+)", out))
+    assert declared <= exported
+    assert L.rt_version().startswith(b"rt355")
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a GPU the product path must fail, never fall back to a CPU renderer."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    rc = L.rt_create(0, ctypes.byref(h))
+    assert rc == -2 and b"no CPU path" in L.rt_last_error(None)
+    import raytracer_amd
+    with pytest.raises(RuntimeError):
+        raytracer_amd.render(4, 4)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raytracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/", "").lower() or f in ("__init__.py",) \
+                    or "import oracle" not in src and "from oracle" not in src, f
+                assert "import oracle" not in src and "from oracle" not in src, f
