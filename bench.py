@@ -64,22 +64,27 @@ def cpu_baseline(wl, target_s=15.0):
     threads = min(cpu_oracle.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 10**6,
                   len(os.sched_getaffinity(0)))
 
-    def run(rows):
-        px = np.stack([np.tile(np.arange(w), len(rows)), np.repeat(rows, w)], 1)
+    from raytracer_amd.scenes import pack_scene
+    p = pack_scene(scene)
+
+    def run_frame(seed):
         t0 = time.perf_counter()
-        o = cpu_oracle.render_scene(scene, w, h, pixels=px, max_depth=D, mode="K", seed=0, threads=threads)
+        o = cpu_oracle.render_pixels(p.geom4[:, :3], p.radius, p.mat4[:, :3], p.spec, p.mat4[:, 3],
+                                     p.lights, p.area_samples, w, h, max_depth=D, mode="K", seed=seed,
+                                     threads=threads)
         dt = time.perf_counter() - t0
-        rays = int(o["trace_levels"].sum()) + 13 * int(o["hit_levels"].sum())
+        rays = int(o["trace_levels"].sum()) + (1 + p.area_samples) * int(o["hit_levels"].sum())
         return rays, dt
 
-    probe_rows = np.arange(0, h, max(1, h // 16))
-    rays, dt = run(probe_rows)
-    per_row = dt / len(probe_rows)
-    k = int(min(h, max(len(probe_rows), target_s / max(per_row, 1e-9))))
-    rows = np.unique(np.linspace(0, h - 1, k).astype(int))
-    rays, dt = run(rows)
+    # whole frames of the workload (seed = frame index) until ~target_s of CPU time is spent
+    rows = np.arange(h)
+    rays = frames = 0
+    dt = 0.0
+    while dt < target_s and frames < 64:
+        r_, d_ = run_frame(frames)
+        rays += r_; dt += d_; frames += 1
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
-                sample=f"{len(rows)} of {h} rows of one frame ({rays} rays, {dt:.1f} s), FP64, OpenMP",
+                sample=f"{frames} whole frames of the workload ({rays} rays, {dt:.1f} s), FP64, OpenMP",
                 python_reference_mrays_1core=PY_REFERENCE_MRAYS)
 
 

@@ -73,8 +73,11 @@ void rt_destroy(rt_ctx* ctx);
 /* Message for the last failure on this context (ctx may be NULL for rt_create failures). */
 const char* rt_last_error(const rt_ctx* ctx);
 
-/* Use the caller's HIP stream (hipStream_t passed as void*; NULL = the context's own stream). */
-int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+/* Select the stream every later call launches on: the caller's hipStream_t passed as void*
+ * (NULL is HIP's legacy default stream, which is what torch.cuda.current_stream().cuda_stream
+ * is by default), or, with use_own_stream != 0, the context's own non-blocking stream (the
+ * state after rt_create). */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream, int use_own_stream);
 int rt_synchronize(rt_ctx* ctx);
 
 /* Upload scene['spheres'] as struct-of-arrays plus the two lights.

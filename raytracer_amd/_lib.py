@@ -38,13 +38,17 @@ def load():
     if not os.path.isfile(_SO):
         raise ImportError(f"{_SO} is missing: build it with `python -m raytracer_amd.build` "
                           "(hipcc --offload-arch=gfx950). rt355 has no CPU fallback.")
+    # torch first: its wheel bundles its own libamdhip64; loading ours afterwards binds to that
+    # already-loaded runtime (same SONAME) so the process has exactly one HIP runtime and
+    # torch tensors / streams are valid inside rt355.
+    import torch  # noqa: F401
     L = ctypes.CDLL(_SO)
     c_int, c_void_p, c_u64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64
     P = ctypes.POINTER
     L.rt_create.argtypes = [c_int, P(c_void_p)]
     L.rt_destroy.argtypes = [c_void_p]; L.rt_destroy.restype = None
     L.rt_last_error.argtypes = [c_void_p]; L.rt_last_error.restype = ctypes.c_char_p
-    L.rt_set_stream.argtypes = [c_void_p, c_void_p]
+    L.rt_set_stream.argtypes = [c_void_p, c_void_p, c_int]
     L.rt_synchronize.argtypes = [c_void_p]
     L.rt_upload_scene.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, P(RtLights)]
     L.rt_render.argtypes = [c_void_p, P(RtCamera), c_int, c_int, c_int, c_int, c_int, c_u64,

@@ -81,28 +81,31 @@ __device__ __forceinline__ int row_of(const RenderParams& p, int lr) {
 
 // ------------------------------------------------------------------------------------------
 // find_nearest_intersection (raytracer.py:152-172) over the LDS-resident sphere list.
-// Half-b form of intersect_sphere (raytracer.py:93-104): with co = C - O, nb = co.D = -b/2,
-// disc' = nb^2 - a*c = disc/4 and t = (nb - sqrt(disc'))/a — every difference from the
-// reference's expressions is an exact power-of-two scaling.  The candidate is compared on the
-// numerator (a > 0 is common to all spheres); strict `<` in index order keeps the lowest index
-// on ties, and t == 0 / t < 0 are rejected as the reference's `if t and ...` does.
+//
+// intersect_sphere (raytracer.py:93-104) in a cancellation-free form.  With co = C - O,
+// nb = co.D (= -b/2), a = D.D, q = nb/a and the perpendicular offset l = co - q*D:
+//     disc/4 = nb^2 - a*c = a*(r^2 - |l|^2)        t = (-b - sqrt(disc))/(2a) = q - sqrt((r^2-|l|^2)/a)
+// Evaluating b^2 - 4ac directly in FP32 loses ~|co|^2 * 1e-6 to cancellation (|co| ~ 20 =>
+// a silhouette jitter visible as flipped shadow samples on ~0.5 % of pixels); r^2 - |l|^2 keeps
+// the error at ~|l| * ulp(|co|).  Strict `<` in index order keeps the lowest index on ties, and
+// t == 0 / t < 0 are rejected as the reference's `if t and ...` does (raytracer.py:102,162).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, int n, float ox, float oy,
-                                            float oz, float dx, float dy, float dz, float a,
-                                            float& best_tn, int& best_i) {
-  best_tn = INFINITY;
+                                            float oz, float dx, float dy, float dz, float inv_a,
+                                            float& best_t, int& best_i) {
+  best_t = INFINITY;
   best_i = -1;
 #pragma unroll 4
   for (int i = 0; i < n; ++i) {
     const float4 s = sg[i];  // wave-uniform address: LDS broadcast read
     const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-    const float nb = fmaf(cz, dz, fmaf(cy, dy, cx * dx));
-    const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -s.w)));
-    const float disc = fmaf(nb, nb, -(a * c));
-    if (disc >= 0.0f) {
-      const float tn = nb - sqrtf(disc);
-      if (tn > 0.0f && tn < best_tn) {
-        best_tn = tn;
+    const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
+    const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
+    const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));  // r^2 - |l|^2
+    if (dl >= 0.0f) {
+      const float t = q - sqrtf(dl * inv_a);
+      if (t > 0.0f && t < best_t) {
+        best_t = t;
         best_i = i;
       }
     }
@@ -130,15 +133,14 @@ __device__ __forceinline__ void trace_path(const RenderParams& p, const float4* 
 
   for (int level = 0; level <= p.max_depth; ++level) {
     ++n_trace;
-    const float a = fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // :95, computed, not assumed 1
-    float best_tn;
+    const float inv_a = 1.0f / fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // :95, computed, not assumed 1
+    float t;
     int bi;
-    nearest_hit(sg, n, ox, oy, oz, dx, dy, dz, a, best_tn, bi);
+    nearest_hit(sg, n, ox, oy, oz, dx, dy, dz, inv_a, t, bi);
     if (level == 0) hit0 = bi;
     if (bi < 0) break;  // :237-238 miss -> black
     ++n_shade;
 
-    const float t = best_tn / a;
     const float4 s = sg[bi];
     const float4 m = p.mat[bi];
     const float spec = p.spec[bi];
@@ -158,7 +160,7 @@ __device__ __forceinline__ void trace_path(const RenderParams& p, const float4* 
     float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
     float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
     for (int base = 0; base < nrays; base += B) {
-      float Lx[B], Ly[B], Lz[B], La[B], Wd[B], Ws[B];
+      float Lx[B], Ly[B], Lz[B], Wd[B], Ws[B];
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const int j = base + k;
@@ -181,13 +183,13 @@ __device__ __forceinline__ void trace_path(const RenderParams& p, const float4* 
         const float vr = fmaf(-2.0f * ndl, vdn, vdl);
         const bool valid = j < nrays;
         Lx[k] = valid ? lx : 0.f; Ly[k] = valid ? ly : 0.f; Lz[k] = valid ? lz : 0.f;
-        La[k] = fmaf(Lz[k], Lz[k], fmaf(Ly[k], Ly[k], Lx[k] * Lx[k]));  // :95 for the shadow ray
         Wd[k] = valid ? fmaxf(0.f, ndl) : 0.f;                           // :188 / :203
         Ws[k] = (valid && spec > 0.f) ? pow50(fmaxf(0.f, vr)) : 0.f;     // :191-193 / :206-208
       }
       // any-hit scan (:185-187, :200-202 with refraction == 0): the B rays share the origin, so
-      // co = C - O and c are per-sphere; hit <=> disc >= 0 and t > 0 <=> disc >= 0, nb > 0, c > 0
-      // (t > 0 <=> nb > sqrt(disc) <=> nb > 0 and a*c > 0) — no sqrt, no divide.
+      // co = C - O and c are per-sphere; hit <=> disc >= 0 and t > 0 <=> r^2 >= |l|^2, nb > 0, c > 0
+      // (t > 0 <=> nb > sqrt(disc) <=> nb > 0 and a*c > 0) — no sqrt, no divide.  L is a unit
+      // vector (a = 1 +- 2e-7); the residual of q = nb along L enters |l|^2 only to second order.
       bool shadowed[B];
 #pragma unroll
       for (int k = 0; k < B; ++k) shadowed[k] = false;
@@ -200,8 +202,9 @@ __device__ __forceinline__ void trace_path(const RenderParams& p, const float4* 
 #pragma unroll
         for (int k = 0; k < B; ++k) {
           const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
-          const float disc = fmaf(nb, nb, -(La[k] * c));
-          shadowed[k] |= (disc >= 0.0f) & (nb > 0.0f) & cpos;
+          const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
+          const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, g.w)));
+          shadowed[k] |= (dl >= 0.0f) & (nb > 0.0f) & cpos;
         }
       }
 #pragma unroll
@@ -512,9 +515,11 @@ void rt_destroy(rt_ctx* ctx) {
   delete ctx;
 }
 
-int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
+int rt_set_stream(rt_ctx* ctx, void* hip_stream, int use_own_stream) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
-  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  // hip_stream == NULL with use_own_stream == 0 is HIP's legacy default stream (what
+  // torch.cuda.current_stream().cuda_stream is unless the caller switched streams).
+  ctx->stream = use_own_stream ? ctx->own_stream : static_cast<hipStream_t>(hip_stream);
   return RT_OK;
 }
 

@@ -65,7 +65,7 @@ class Renderer:
         and RCCL collectives order against the render kernels without extra syncs."""
         torch = _torch()
         s = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self._L.rt_set_stream(self._h, ctypes.c_void_p(s)))
+        self._check(self._L.rt_set_stream(self._h, ctypes.c_void_p(s), 0))
 
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))
