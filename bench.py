@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="frames per step (batch)")
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--kernel", default="stream", choices=["stream", "pixel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -129,6 +130,7 @@ def main():
     packed = pack_scene(scene)
     r = Renderer(local_rank)
     r.upload_scene(packed)
+    r.set_kernel(args.kernel)
 
     rows_max = tiling.max_local_rows(h, tr, world)
     slab_bytes = rows_max * w * 3
@@ -141,14 +143,16 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
+    from raytracer_amd.scenes import Camera
+    cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
+
     def step(i, timed_idx=None):
         if timed_idx is not None:
             ev[timed_idx][0].record()
-        for f in range(F):
-            # N = 1: the rank owns every row, so its packed slab IS the frame
-            out = frames_out[f] if world == 1 else slab[f].view(rows_max, w, 3)
-            r.render_rows(w, h, args.samples, tile_rows=tr, tile_first=rank, tile_stride=world,
-                          max_depth=D, rng_mode="K", seed=i * F + f, out=out)
+        # N = 1: the rank owns every row, so its packed slab IS the frame batch
+        out = frames_out if world == 1 else slab.view(F, rows_max, w, 3)
+        r.render_frames(cams, range(i * F, (i + 1) * F), w, h, args.samples, max_depth=D, rng_mode="K",
+                        out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
         if timed_idx is not None:
             ev[timed_idx][1].record()
         if world > 1:
@@ -176,7 +180,8 @@ def main():
     rc = r.ray_counts()
     stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * F)        # per render launch
+    launches_per_step = -(-F // 16) * args.samples                            # <= 16 frames per launch
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
     kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -187,7 +192,7 @@ def main():
 
     if rank == 0:
         # per-launch (per rank) algorithmic flops of rt_render_kernel on rank 0
-        launches = args.steps * F
+        launches = args.steps * launches_per_step
         fl = algorithmic_flops(rc["total"], rc["shaded_hits"], n_sph, packed.area_samples) / launches
         achieved = fl / (kern_ms * 1e-3) / 1e12
         out = {
@@ -211,7 +216,7 @@ def main():
             "mpixels_per_s": primary / dt / 1e6,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "rt_render_kernel", "kernel_ms": kern_ms,
+                         "kernel": f"rt_{args.kernel}_kernel", "kernel_ms": kern_ms,
                          "flops_per_launch": fl,
                          "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d; "
                                  "HBM traffic is the framebuffer only (3 B/pixel)"},

@@ -80,6 +80,15 @@ const char* rt_last_error(const rt_ctx* ctx);
 int rt_set_stream(rt_ctx* ctx, void* hip_stream, int use_own_stream);
 int rt_synchronize(rt_ctx* ctx);
 
+/* Tuning / diagnostic options (no reference counterpart).
+ *   RT_OPT_KERNEL: RT_KERNEL_STREAM (default) = workgroup work-queue kernel that compacts hits into
+ *   dense shading batches; RT_KERNEL_PIXEL = one thread per pixel, whole path in one loop (kept
+ *   as the baseline for divergence counters).  Both compute the same arithmetic per ray. */
+#define RT_OPT_KERNEL 1
+#define RT_KERNEL_STREAM 0
+#define RT_KERNEL_PIXEL 1
+int rt_set_option(rt_ctx* ctx, int option, int value);
+
 /* Upload scene['spheres'] as struct-of-arrays plus the two lights.
  * Replaces the reference's AoS Python objects Sphere/Material (raytracer.py:42-54) and the
  * `scene` dict (raytracer.py:78-87).
@@ -106,6 +115,16 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samp
 int rt_render_rows(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
                    int max_depth, int rng_mode, uint64_t seed, int tile_rows, int tile_first,
                    int tile_stride, uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out);
+
+/* rt_render_rows for a batch of frames (frame f: cams[f], seeds[f]) of one uploaded scene, up to 16
+ * frames per kernel launch.  Frame f is written at out_rgb + f * stride * 3 bytes (out_hit + f *
+ * stride ints), stride = out_frame_stride_px pixels, or n_local_rows * width when that is 0.  This
+ * is what a rank of a multi-GPU animation / benchmark batch calls (row tiles of every frame into
+ * equally sized slabs, one gather). */
+int rt_render_frames_rows(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames,
+                          int width, int height, int samples, int max_depth, int rng_mode,
+                          int tile_rows, int tile_first, int tile_stride, int64_t out_frame_stride_px,
+                          uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out);
 
 /* render_chunk((x_start, x_end, y_start, y_end, width, height, scene, samples))
  * (raytracer.py:299-308): clamped, UNquantised colour of a sub-rectangle.

@@ -11,12 +11,14 @@ _SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librt355
 _lib = None
 
 RT_RNG_CONSTANT, RT_RNG_KEYED = 0, 1
+RT_OPT_KERNEL, RT_KERNEL_STREAM, RT_KERNEL_PIXEL = 1, 0, 1
 RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT: RT_RNG_CONSTANT,
              "K": RT_RNG_KEYED, "keyed": RT_RNG_KEYED}
 
 #: every symbol include/rt355.h declares (tests check the .so exports all of them)
 SYMBOLS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize",
-           "rt_upload_scene", "rt_render", "rt_render_rows", "rt_render_chunk", "rt_render_frames",
+           "rt_set_option", "rt_upload_scene", "rt_render", "rt_render_rows", "rt_render_frames_rows",
+           "rt_render_chunk", "rt_render_frames",
            "rt_scatter_rows", "rt_get_ray_counts", "rt_reset_ray_counts", "rt_version")
 
 
@@ -55,6 +57,10 @@ def load():
                             c_void_p, c_void_p]
     L.rt_render_rows.argtypes = [c_void_p, P(RtCamera), c_int, c_int, c_int, c_int, c_int, c_u64,
                                  c_int, c_int, c_int, c_void_p, c_void_p, P(c_int)]
+    L.rt_render_frames_rows.argtypes = [c_void_p, P(RtCamera), P(c_u64), c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p,
+                                        P(c_int)]
+    L.rt_set_option.argtypes = [c_void_p, c_int, c_int]
     L.rt_render_chunk.argtypes = [c_void_p, P(RtCamera), c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_u64, c_void_p]
     L.rt_render_frames.argtypes = [c_void_p, P(RtCamera), P(c_u64), c_int, c_int, c_int, c_int,

@@ -1,14 +1,19 @@
 // rt355 — hand-written HIP kernels (gfx950 / MI355X) + C ABI for the per-pixel render path of
 // aram-ap/RayTracer (raytracer.py:93-104, 139-140, 152-211, 232-260, 289-325).
 //
-// This is not a translation of the reference's Python: the recursion is an iterative
-// throughput loop, the 13 shadow rays of one shading point are traced together against each
-// sphere (shared origin => shared `C - O` and `c` terms, sqrt-free any-hit test), the sphere
-// geometry is staged once per workgroup into LDS and read back as wave-uniform broadcasts, and
-// pixels are packed to RGB bytes through an LDS tile so global stores are whole dwords.
+// This is not a translation of the reference's Python:
+//   * recursion -> iterative throughput accumulator, and further -> a workgroup-level work queue
+//     in LDS: primary hits and reflected hits are compacted into dense batches, so the shadow-ray
+//     loop (13 of every 14 rays) runs with full 64-lane waves whatever the hit pattern;
+//   * the 13 shadow rays of one shading point are traced together against each sphere (shared
+//     origin => shared `C - O`, sqrt-free any-hit test, branch-free min/max accumulation);
+//   * sphere geometry is staged once per workgroup into LDS and read back as wave-uniform
+//     broadcasts; finished pixels are staged in LDS and leave as whole-dword packed-RGB stores;
+//   * up to 16 frames go in one launch so small frames still fill 256 CUs.
 // DESIGN.md describes the layout and the roofline; include/rt355.h documents the ABI.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -21,7 +26,7 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// kernel parameters (passed by value: they land in SGPRs via the kernarg segment)
+// kernel parameters (passed by value: the kernarg segment is read with scalar loads)
 // ------------------------------------------------------------------------------------------
 struct DevLights {
   float ppos[3], pcol[3], pint;
@@ -29,31 +34,43 @@ struct DevLights {
   int ns;
 };
 
+constexpr int kMaxBatch = 16;  // frames per launch
+
 struct RenderParams {
-  rt_camera cam;
   DevLights L;
   int width, height;     // full image, defines the primary rays (raytracer.py:290-295)
   int x0, nx;            // column window [x0, x0+nx)
   int n_rows;            // local rows rendered by this launch
   int tile_rows, tile_first, tile_stride;  // local row lr -> image row, see row_of()
   int y0;                // extra row offset (render_chunk)
-  int samples, max_depth, rng_mode;
-  uint32_t seed32;
+  int sample_index, n_samples;  // this launch traces sample `sample_index` of n_samples
+  int max_depth;
   int n_spheres;
+  int n_frames, strips_x, strips_y;
   const float4* geom;    // cx cy cz r^2
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
-  uint8_t* out_rgb;      // [n_rows][nx][3] or null
-  float* out_f32;        // [n_rows][nx][3] or null (render_chunk)
-  int32_t* out_hit;      // [n_rows][nx] or null
+  uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
+  float* out_f32;        // [frame][n_rows][nx][3] or null (render_chunk)
+  int32_t* out_hit;      // [frame][n_rows][nx] or null
+  float* accum;          // [frame][n_rows][nx][3] running sum over samples (n_samples > 1)
   unsigned long long* counters;  // [kCounterSlots][8]
+  long long frame_stride_px;     // pixels between frames in out_*
+  long long accum_stride_px;     // pixels between frames in accum
+  rt_camera cams[kMaxBatch];
+  uint32_t seeds[kMaxBatch];
 };
 
 constexpr int kBlock = 256;        // 4 waves
-constexpr int kTileW = 32;         // pixels per workgroup tile: 32 x 8, one 8x8 square per wave
-constexpr int kTileH = 8;
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 cache lines
 constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (raytracer.py:80)
+
+// pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
+constexpr int kTileW = 32, kTileH = 8;
+// stream kernel: 64 x 32 pixel strip per workgroup, processed as 32 tiles of 8 x 8
+constexpr int kStripW = 64, kStripH = 32, kStripTiles = 32, kStripPix = kStripW * kStripH;
+constexpr int kQueueCap = 512;     // >= 2 * kBlock - 1
+constexpr int kQueueFields = 13;   // P(3) D(3) T(3) acc(3) meta(1)
 
 // ------------------------------------------------------------------------------------------
 // keyed RNG — identical to oracle/ref_harness.py / oracle/rt_oracle.cpp
@@ -63,8 +80,9 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   return h;
 }
 __device__ __forceinline__ uint32_t mix(uint32_t h, uint32_t v) { return fmix32(h + 0x9E3779B9u + v); }
-__device__ __forceinline__ float draw(int mode, uint32_t level_key, uint32_t i) {
-  if (mode == RT_RNG_CONSTANT) return 0.5f;
+template <int MODE>
+__device__ __forceinline__ float draw(uint32_t level_key, uint32_t i) {
+  if (MODE == RT_RNG_CONSTANT) return 0.5f;
   return float(fmix32(level_key + i * 0x9E3779B9u + 0x7F4A7C15u) >> 8) * (1.0f / 16777216.0f);
 }
 
@@ -91,8 +109,9 @@ __device__ __forceinline__ int row_of(const RenderParams& p, int lr) {
 // t == 0 / t < 0 are rejected as the reference's `if t and ...` does (raytracer.py:102,162).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, int n, float ox, float oy,
-                                            float oz, float dx, float dy, float dz, float inv_a,
-                                            float& best_t, int& best_i) {
+                                            float oz, float dx, float dy, float dz, float& best_t,
+                                            int& best_i) {
+  const float inv_a = 1.0f / fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // :95, computed, not assumed 1
   best_t = INFINITY;
   best_i = -1;
 #pragma unroll 4
@@ -113,235 +132,447 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, int n
 }
 
 // ------------------------------------------------------------------------------------------
-// One path: trace_ray (raytracer.py:232-260) as an iterative loop with a throughput
-// accumulator:  C_d = (m_d (1-r_d) + r_d C_{d+1}) * l_d   =>
-//   acc += T * m_d (1-r_d) * l_d ;  T *= r_d * l_d ;  stop on miss, r_d == 0 or d == D.
-// compute_lighting (raytracer.py:174-211) is evaluated in forward order: l_d depends only on the
-// hit at level d.
+// compute_lighting (raytracer.py:174-211) at one hit: point light + L.ns area-light samples,
+// B shadow rays at a time.  Returns the light colour l (to be multiplied into the surface colour).
+//
+// Any-hit scan (:185-187, :200-202 with refraction == 0).  The B rays share their origin S, so
+// co = C - S and c = |co|^2 - r^2 are per-sphere; per (ray, sphere):
+//     hit <=> disc >= 0 and t > 0 <=> r^2 >= |l|^2 and nb > 0 and c > 0        (no sqrt, no divide)
+// (t > 0 <=> nb > sqrt(disc) <=> nb > 0 and a*c > 0; with c > 0 and nb == 0, r^2 - |l|^2 = -c < 0,
+// so `nb >= 0` is equivalent).  c <= 0 is folded in by replacing r^2 with -inf for that sphere, and
+// the verdict is accumulated branch-free as  m_k = max(m_k, min(r^2 - |l|^2, nb))  (shadowed <=>
+// m_k >= 0).  L is a unit vector (a = 1 +- 2e-7): the residual of q = nb along L enters |l|^2 only
+// to second order.
 // ------------------------------------------------------------------------------------------
-template <int B>
-__device__ __forceinline__ void trace_path(const RenderParams& p, const float4* __restrict__ sg,
-                                           float ox, float oy, float oz, float dx, float dy, float dz,
-                                           uint32_t pixel_key, float& out_r, float& out_g, float& out_b,
-                                           int& hit0, uint32_t& n_trace, uint32_t& n_shade) {
-  float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
-  float tp_r = 1.f, tp_g = 1.f, tp_b = 1.f;
-  const int n = p.n_spheres;
-  const int nrays = 1 + p.L.ns;
-  const float inv_ns = 1.0f / float(p.L.ns);
-  hit0 = -1;
-
-  for (int level = 0; level <= p.max_depth; ++level) {
-    ++n_trace;
-    const float inv_a = 1.0f / fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // :95, computed, not assumed 1
-    float t;
-    int bi;
-    nearest_hit(sg, n, ox, oy, oz, dx, dy, dz, inv_a, t, bi);
-    if (level == 0) hit0 = bi;
-    if (bi < 0) break;  // :237-238 miss -> black
-    ++n_shade;
-
-    const float4 s = sg[bi];
-    const float4 m = p.mat[bi];
-    const float spec = p.spec[bi];
-    // hit point and normal (:165-166, :139-140)
-    const float px = fmaf(dx, t, ox), py = fmaf(dy, t, oy), pz = fmaf(dz, t, oz);
-    float nx = px - s.x, ny = py - s.y, nz = pz - s.z;
-    {
-      const float inv = 1.0f / sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
-      nx *= inv; ny *= inv; nz *= inv;
-    }
-    // shadow-ray origin (:184, :199) — also the reflection origin (:247)
-    const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-    const float vdn = -(fmaf(dz, nz, fmaf(dy, ny, dx * nx)));  // view . normal, view = -D (:257)
-
-    // ---- compute_lighting: all shadow rays of this point, B at a time -----------------------
-    const uint32_t level_key = mix(pixel_key, uint32_t(level + 1));
-    float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
-    float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
-    for (int base = 0; base < nrays; base += B) {
-      float Lx[B], Ly[B], Lz[B], Wd[B], Ws[B];
+template <int MODE, int B>
+__device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg, int n,
+                                         float px, float py, float pz, float nx, float ny, float nz,
+                                         float dx, float dy, float dz, float sx, float sy, float sz,
+                                         float mr, float mg, float mb, float spec, uint32_t level_key,
+                                         float& lr, float& lg, float& lb) {
+  const int nrays = 1 + L.ns;
+  const float vdn = -(fmaf(dz, nz, fmaf(dy, ny, dx * nx)));  // view . normal, view = -D (:257)
+  float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
+  float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
+  for (int base = 0; base < nrays; base += B) {
+    float Lx[B], Ly[B], Lz[B], m[B];
 #pragma unroll
-      for (int k = 0; k < B; ++k) {
-        const int j = base + k;
-        float lx, ly, lz;
-        if (j == 0) {  // scene['global_light'] (:198)
-          lx = p.L.ppos[0]; ly = p.L.ppos[1]; lz = p.L.ppos[2];
-        } else {       // area-light sample j-1 (:180-182)
-          const float ru = draw(p.rng_mode, level_key, uint32_t(2 * (j - 1))) - 0.5f;
-          const float rv = draw(p.rng_mode, level_key, uint32_t(2 * (j - 1) + 1)) - 0.5f;
-          lx = fmaf(p.L.av[0], rv, fmaf(p.L.au[0], ru, p.L.apos[0]));
-          ly = fmaf(p.L.av[1], rv, fmaf(p.L.au[1], ru, p.L.apos[1]));
-          lz = fmaf(p.L.av[2], rv, fmaf(p.L.au[2], ru, p.L.apos[2]));
-        }
-        lx -= px; ly -= py; lz -= pz;                        // :183 / :198
-        const float inv = 1.0f / sqrtf(fmaf(lz, lz, fmaf(ly, ly, lx * lx)));
-        lx *= inv; ly *= inv; lz *= inv;
-        const float ndl = fmaf(nz, lz, fmaf(ny, ly, nx * lx));
-        // view . (L - N*(2 L.N))  (:192-193 / :207-208; the sign of R is the reference's)
-        const float vdl = -(fmaf(dz, lz, fmaf(dy, ly, dx * lx)));
-        const float vr = fmaf(-2.0f * ndl, vdn, vdl);
-        const bool valid = j < nrays;
-        Lx[k] = valid ? lx : 0.f; Ly[k] = valid ? ly : 0.f; Lz[k] = valid ? lz : 0.f;
-        Wd[k] = valid ? fmaxf(0.f, ndl) : 0.f;                           // :188 / :203
-        Ws[k] = (valid && spec > 0.f) ? pow50(fmaxf(0.f, vr)) : 0.f;     // :191-193 / :206-208
+    for (int k = 0; k < B; ++k) {
+      const int j = base + k;
+      float lx, ly, lz;
+      if (j == 0) {  // scene['global_light'] (:198)
+        lx = L.ppos[0]; ly = L.ppos[1]; lz = L.ppos[2];
+      } else {       // area-light sample j-1 (:180-182)
+        const float ru = draw<MODE>(level_key, uint32_t(2 * (j - 1))) - 0.5f;
+        const float rv = draw<MODE>(level_key, uint32_t(2 * (j - 1) + 1)) - 0.5f;
+        lx = fmaf(L.av[0], rv, fmaf(L.au[0], ru, L.apos[0]));
+        ly = fmaf(L.av[1], rv, fmaf(L.au[1], ru, L.apos[1]));
+        lz = fmaf(L.av[2], rv, fmaf(L.au[2], ru, L.apos[2]));
       }
-      // any-hit scan (:185-187, :200-202 with refraction == 0): the B rays share the origin, so
-      // co = C - O and c are per-sphere; hit <=> disc >= 0 and t > 0 <=> r^2 >= |l|^2, nb > 0, c > 0
-      // (t > 0 <=> nb > sqrt(disc) <=> nb > 0 and a*c > 0) — no sqrt, no divide.  L is a unit
-      // vector (a = 1 +- 2e-7); the residual of q = nb along L enters |l|^2 only to second order.
-      bool shadowed[B];
-#pragma unroll
-      for (int k = 0; k < B; ++k) shadowed[k] = false;
+      lx -= px; ly -= py; lz -= pz;                        // :183 / :198
+      // a ray beyond the light's sample count gets L = 0: it can never be shadowed and every
+      // weight below (N.L, V.R) is then 0 too
+      const float inv = (j < nrays) ? 1.0f / sqrtf(fmaf(lz, lz, fmaf(ly, ly, lx * lx))) : 0.0f;
+      Lx[k] = lx * inv; Ly[k] = ly * inv; Lz[k] = lz * inv;
+      m[k] = -1.0f;
+    }
 #pragma unroll 2
-      for (int i = 0; i < n; ++i) {
-        const float4 g = sg[i];
-        const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
-        const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
-        const bool cpos = c > 0.0f;
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-          const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
-          const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
-          const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, g.w)));
-          shadowed[k] |= (dl >= 0.0f) & (nb > 0.0f) & cpos;
-        }
-      }
+    for (int i = 0; i < n; ++i) {
+      const float4 g = sg[i];
+      const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
+      const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
+      const float r2 = (c > 0.0f) ? g.w : -INFINITY;
 #pragma unroll
       for (int k = 0; k < B; ++k) {
-        const float wd = shadowed[k] ? 0.f : Wd[k];
-        const float ws = shadowed[k] ? 0.f : Ws[k];
-        if (k == 0 && base == 0) { pd = wd; ps = ws; }
-        else { ad += wd; as += ws; }
+        const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
+        const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
+        const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
+        m[k] = __builtin_fmaxf(m[k], __builtin_fminf(dl, nb));
       }
     }
-    // :204 + :209 + :189/:194/:196
-    const float pk = p.L.pint * pd, psk = p.L.pint * spec * ps;
-    const float ak = p.L.aint * ad * inv_ns, ask = p.L.aint * spec * as * inv_ns;
-    const float lr = fmaf(m.x * p.L.pcol[0], pk, p.L.pcol[0] * psk) + p.L.acol[0] * (ak + ask);
-    const float lg = fmaf(m.y * p.L.pcol[1], pk, p.L.pcol[1] * psk) + p.L.acol[1] * (ak + ask);
-    const float lb = fmaf(m.z * p.L.pcol[2], pk, p.L.pcol[2] * psk) + p.L.acol[2] * (ak + ask);
-
-    // :242-249, :258 folded into the accumulator
-    const float refl = m.w;
-    const float keep = 1.0f - refl;
-    acc_r = fmaf(tp_r * (m.x * keep), lr, acc_r);
-    acc_g = fmaf(tp_g * (m.y * keep), lg, acc_g);
-    acc_b = fmaf(tp_b * (m.z * keep), lb, acc_b);
-    if (!(refl > 0.0f)) break;  // :245 no reflection ray
-    tp_r *= refl * lr; tp_g *= refl * lg; tp_b *= refl * lb;
-    // reflection ray (:246-247), direction not renormalised
-    const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));
-    dx = fmaf(-dn2, nx, dx); dy = fmaf(-dn2, ny, dy); dz = fmaf(-dn2, nz, dz);
-    ox = sx; oy = sy; oz = sz;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const float ndl = fmaf(nz, Lz[k], fmaf(ny, Ly[k], nx * Lx[k]));
+      // view . (L - N*(2 L.N))  (:192-193 / :207-208; the sign of R is the reference's)
+      const float vdl = -(fmaf(dz, Lz[k], fmaf(dy, Ly[k], dx * Lx[k])));
+      const float vr = fmaf(-2.0f * ndl, vdn, vdl);
+      const bool lit = m[k] < 0.0f;                                  // :187 / :202
+      const float wd = lit ? fmaxf(0.f, ndl) : 0.f;                  // :188 / :203
+      const float ws = lit ? pow50(fmaxf(0.f, vr)) : 0.f;            // :193 / :208
+      if (k == 0) {
+        if (base == 0) { pd = wd; ps = ws; } else { ad += wd; as += ws; }
+      } else { ad += wd; as += ws; }
+    }
   }
-  out_r = acc_r; out_g = acc_g; out_b = acc_b;
+  if (!(spec > 0.0f)) { ps = 0.f; as = 0.f; }                        // :191 / :206
+  // :204 + :209 + :189/:194/:196
+  const float inv_ns = 1.0f / float(L.ns);
+  const float pk = L.pint * pd, psk = L.pint * spec * ps;
+  const float ak = L.aint * ad * inv_ns, ask = L.aint * spec * as * inv_ns;
+  lr = fmaf(mr * L.pcol[0], pk, L.pcol[0] * psk) + L.acol[0] * (ak + ask);
+  lg = fmaf(mg * L.pcol[1], pk, L.pcol[1] * psk) + L.acol[1] * (ak + ask);
+  lb = fmaf(mb * L.pcol[2], pk, L.pcol[2] * psk) + L.acol[2] * (ak + ask);
+}
+
+// One shaded hit (trace_ray :240-258 without the recursion): hit point P on sphere `idx`, incoming
+// direction D.  Folds the level into the throughput accumulator
+//     C_d = (m_d (1-r_d) + r_d C_{d+1}) * l_d   =>   acc += T * m_d (1-r_d) * l_d ;  T *= r_d * l_d
+// and produces the reflection ray (:246-247, direction not renormalised).  Returns true if the
+// path continues (r_d > 0).
+template <int MODE>
+__device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* __restrict__ sg, int idx,
+                                          float px, float py, float pz, float& dx, float& dy, float& dz,
+                                          uint32_t level_key, float& tr, float& tg, float& tb,
+                                          float& ar, float& ag, float& ab, float& ox, float& oy,
+                                          float& oz) {
+  const float4 s = sg[idx];
+  const float4 m = p.mat[idx];
+  const float spec = p.spec[idx];
+  float nx = px - s.x, ny = py - s.y, nz = pz - s.z;               // :139-140
+  {
+    const float inv = 1.0f / sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+    nx *= inv; ny *= inv; nz *= inv;
+  }
+  // shadow-ray origin (:184, :199) — also the reflection origin (:247)
+  const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
+  float lr, lg, lb;
+  lighting<MODE, kShadowBatch>(p.L, sg, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+                               m.x, m.y, m.z, spec, level_key, lr, lg, lb);
+  const float refl = m.w;
+  const float keep = 1.0f - refl;                                    // :249
+  ar = fmaf(tr * (m.x * keep), lr, ar);
+  ag = fmaf(tg * (m.y * keep), lg, ag);
+  ab = fmaf(tb * (m.z * keep), lb, ab);
+  if (!(refl > 0.0f)) return false;                                  // :245
+  tr *= refl * lr; tg *= refl * lg; tb *= refl * lb;
+  const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));      // :246
+  dx = fmaf(-dn2, nx, dx); dy = fmaf(-dn2, ny, dy); dz = fmaf(-dn2, nz, dz);
+  ox = sx; oy = sy; oz = sz;                                         // :247
+  return true;
+}
+
+// primary ray of pixel (x, y), sample `sidx` (render_pixel, raytracer.py:290-295)
+template <int MODE>
+__device__ __forceinline__ void primary_ray(const RenderParams& p, const rt_camera& cam, uint32_t seed32,
+                                            int x, int y, int sidx, uint32_t& pixel_key, float& dx,
+                                            float& dy, float& dz) {
+  const float fw = float(p.width), fh = float(p.height);
+  const float aspect = fw / fh;                                                               // :290
+  pixel_key = mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(sidx));
+  const uint32_t jk = mix(pixel_key, 0u);
+  const float u = ((float(x) + draw<MODE>(jk, 0u)) / fw) * 2.0f - 1.0f;                       // :293
+  const float v = -(((float(y) + draw<MODE>(jk, 1u)) / fh) * 2.0f - 1.0f) / aspect;           // :294
+  dx = fmaf(cam.up[0], v, cam.right[0] * u) + cam.forward[0];
+  dy = fmaf(cam.up[1], v, cam.right[1] * u) + cam.forward[1];
+  dz = fmaf(cam.up[2], v, cam.right[2] * u) + cam.forward[2];
+  const float inv = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));                         // :295
+  dx *= inv; dy *= inv; dz *= inv;
+}
+
+__device__ __forceinline__ uint32_t pack_rgbx(float r, float g, float b) {
+  // :318 clamp, :325 (image*255).astype(uint8): truncation toward zero
+  r = fminf(1.0f, fmaxf(0.0f, r)); g = fminf(1.0f, fmaxf(0.0f, g)); b = fminf(1.0f, fmaxf(0.0f, b));
+  return uint32_t(r * 255.0f) | (uint32_t(g * 255.0f) << 8) | (uint32_t(b * 255.0f) << 16);
+}
+
+// Finished sample of a pixel: fold it into the running mean over samples (render_pixel :296-297)
+// and, on the last sample, emit the pixel.  `gpix` indexes out_*, `apix` accum (frame offsets included).
+__device__ __forceinline__ void finish_pixel(const RenderParams& p, long long gpix, long long apix,
+                                             float r, float g, float b, uint32_t* __restrict__ stage_slot) {
+  if (p.n_samples > 1) {
+    float* a = p.accum + apix * 3;
+    if (p.sample_index > 0) { r += a[0]; g += a[1]; b += a[2]; }       // color = color + trace (:296)
+    if (p.sample_index + 1 < p.n_samples) { a[0] = r; a[1] = g; a[2] = b; return; }
+    const float inv_s = 1.0f / float(p.n_samples);                      // :297
+    r *= inv_s; g *= inv_s; b *= inv_s;
+  }
+  if (p.out_f32) {                                                      // render_chunk (:305)
+    float* o = p.out_f32 + gpix * 3;
+    o[0] = fminf(1.0f, fmaxf(0.0f, r)); o[1] = fminf(1.0f, fmaxf(0.0f, g)); o[2] = fminf(1.0f, fmaxf(0.0f, b));
+  }
+  *stage_slot = pack_rgbx(r, g, b);
+}
+
+__device__ __forceinline__ void flush_counters(const RenderParams& p, unsigned int* s_cnt, unsigned slot_id,
+                                               unsigned long long primaries) {
+  const unsigned int nt = s_cnt[0], nsd = s_cnt[1];
+  unsigned long long* slot = p.counters + size_t(slot_id % kCounterSlots) * 8;
+  if (nt) atomicAdd(slot + 0, (unsigned long long)nt);
+  if (nsd) {
+    atomicAdd(slot + 1, (unsigned long long)nsd);
+    atomicAdd(slot + 3, (unsigned long long)nsd * (unsigned long long)(1 + p.L.ns));
+  }
+  if (primaries) atomicAdd(slot + 2, primaries);
+}
+
+// Store a staged tile of `rows` x `cols` pixels (LDS, one RGBX word per pixel, row pitch
+// `pitch` words) as packed RGB bytes at out[(row0 + r) * nx + col0 + c].  Whole dwords when the
+// tile is full width and the rows are dword aligned, bytes otherwise.
+template <int TILE_W>
+__device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const uint32_t* __restrict__ stage,
+                                               int nx, int row0, int col0, int rows, int cols, int tid) {
+  const bool aligned = (cols == TILE_W) && ((nx & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+  if (aligned) {
+    constexpr int kWordsPerRow = TILE_W * 3 / 4;
+    for (int i = tid; i < rows * kWordsPerRow; i += kBlock) {
+      const int r = i / kWordsPerRow, w = i - r * kWordsPerRow;
+      uint32_t val = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int byte = 4 * w + k, c = byte / 3, ch = byte - 3 * c;
+        val |= ((stage[r * TILE_W + c] >> (8 * ch)) & 0xFFu) << (8 * k);
+      }
+      *reinterpret_cast<uint32_t*>(out + (size_t(row0 + r) * nx + col0) * 3 + size_t(w) * 4) = val;
+    }
+  } else {
+    for (int i = tid; i < rows * cols * 3; i += kBlock) {
+      const int r = i / (cols * 3), byte = i - r * (cols * 3), c = byte / 3, ch = byte - 3 * c;
+      out[(size_t(row0 + r) * nx + col0) * 3 + byte] = uint8_t(stage[r * TILE_W + c] >> (8 * ch));
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
-// render / render_chunk / render_pixel (raytracer.py:289-325): one thread per pixel, one 8x8
-// pixel square per wave, 32x8 per workgroup.
+// STREAM KERNEL (default).  One workgroup renders a 64 x 32 pixel strip of one frame.
+//
+//   fill phase : the 4 waves each trace the primary rays of one 8x8 tile (all 64 lanes active);
+//                misses are finished at once, hits are compacted (wave ballot + one LDS atomic per
+//                wave) into the workgroup's queue of hit records in LDS.
+//   shade phase: once >= 256 records are queued (or no tile is left) each thread pops one record:
+//                compute_lighting with its 13 x N shadow tests, throughput update, reflection ray,
+//                nearest-hit scan of that ray; a new hit goes back into the queue, anything else
+//                finishes the pixel.  Popping from the tail keeps deep levels ahead of new work,
+//                so the queue never holds more than 511 records.
+// Lanes therefore only idle in the last partial batch of a strip, instead of wherever a wave's
+// pixels miss or die at different depths (the pixel kernel below, kept for A/B evidence).
+// Finished pixels are staged as RGBX words in LDS and leave as whole-dword packed-RGB rows.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void rt_render_kernel(const RenderParams p) {
+struct Queue {
+  float* f;        // kQueueFields arrays of kQueueCap words
+  __device__ __forceinline__ float& at(int field, int i) const { return f[field * kQueueCap + i]; }
+};
+
+// wave-aggregated reservation of queue slots: returns this lane's slot (valid if `want`)
+__device__ __forceinline__ int queue_reserve(bool want, unsigned int* s_push, int base) {
+  const unsigned long long mask = __ballot(want);
+  const int lane = threadIdx.x & 63;
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  int start = 0;
+  if (mask != 0ull) {
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) start = int(atomicAdd(s_push, (unsigned int)__popcll(mask)));
+    start = __shfl(start, leader);
+  }
+  return base + start + rank;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);
   const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
-  unsigned char* s_tile = smem + geom_bytes;                       // [8][96] bytes
-  unsigned int* s_cnt = reinterpret_cast<unsigned int*>(s_tile + kTileH * kTileW * 3);  // [2]
+  Queue q{reinterpret_cast<float*>(smem + geom_bytes)};
+  uint32_t* stage = reinterpret_cast<uint32_t*>(smem + geom_bytes + kQueueFields * kQueueCap * 4);
+  unsigned int* s_push = reinterpret_cast<unsigned int*>(stage + kStripPix);  // [3] rotating counters
+  unsigned int* s_cnt = s_push + 4;                                           // [2] ray statistics
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
+  if (tid < 3) s_push[tid] = 0u;
+  if (tid < 2) s_cnt[tid] = 0u;
+
+  // workgroup -> (frame, strip)
+  const int strips = p.strips_x * p.strips_y;
+  const int frame = blockIdx.x / strips;
+  const int strip = blockIdx.x - frame * strips;
+  const int strip_y = strip / p.strips_x, strip_x = strip - strip_y * p.strips_x;
+  const int col0 = strip_x * kStripW, row0 = strip_y * kStripH;     // window coordinates
+  const int cols = min(kStripW, p.nx - col0), rows = min(kStripH, p.n_rows - row0);
+  const rt_camera& cam = p.cams[frame];
+  const uint32_t seed32 = p.seeds[frame];
+  const long long frame_px = (long long)frame * p.frame_stride_px;
+  const long long accum_px = (long long)frame * p.accum_stride_px;
+  __syncthreads();
+
+  uint32_t n_trace = 0, n_shade = 0;
+  int q_count = 0;   // uniform across the workgroup
+  int fill = 0;      // next group of 4 tiles
+  int phase = 0;     // selects the rotating push counter
+  constexpr int kFillSteps = kStripTiles / 4;
+
+  for (;;) {
+    // ------------------------------ fill -------------------------------------------------
+    while (q_count < kBlock && fill < kFillSteps) {
+      unsigned int* push = s_push + (phase % 3);
+      if (tid == 0) s_push[(phase + 1) % 3] = 0u;
+      const int tile = fill * 4 + wave;
+      const int lx = (tile & 7) * 8 + (lane & 7), ly = (tile >> 3) * 8 + (lane >> 3);
+      const bool active = (lx < cols) && (ly < rows);
+      bool hit = false;
+      float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+      int idx = -1;
+      if (active) {
+        const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
+        uint32_t pixel_key;
+        primary_ray<MODE>(p, cam, seed32, x, y, p.sample_index, pixel_key, dx, dy, dz);
+        float t;
+        ++n_trace;
+        nearest_hit(sg, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+        hit = idx >= 0;
+        const long long gpix = frame_px + (long long)(row0 + ly) * p.nx + (col0 + lx);
+        if (p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[gpix] = idx;
+        if (hit) {                                                   // :165
+          px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);
+        } else {
+          finish_pixel(p, gpix, gpix - frame_px + accum_px, 0.f, 0.f, 0.f,
+                       &stage[ly * kStripW + lx]);                 // :237-238 miss -> black
+        }
+      }
+      const int slot = queue_reserve(hit, push, q_count);
+      if (hit) {
+        q.at(0, slot) = px; q.at(1, slot) = py; q.at(2, slot) = pz;
+        q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
+        q.at(6, slot) = 1.f; q.at(7, slot) = 1.f; q.at(8, slot) = 1.f;
+        q.at(9, slot) = 0.f; q.at(10, slot) = 0.f; q.at(11, slot) = 0.f;
+        // meta: local pixel (11 bits) | level (7 bits) | sphere index (13 bits)
+        q.at(12, slot) = __uint_as_float(uint32_t(ly * kStripW + lx) | (0u << 11) | (uint32_t(idx) << 18));
+      }
+      __syncthreads();
+      q_count += int(*push);
+      ++fill;
+      ++phase;
+    }
+    if (q_count == 0) break;
+
+    // ------------------------------ shade ------------------------------------------------
+    {
+      unsigned int* push = s_push + (phase % 3);
+      if (tid == 0) s_push[(phase + 1) % 3] = 0u;
+      const int n_pop = min(kBlock, q_count);
+      const int base = q_count - n_pop;
+      const bool have = tid < n_pop;
+      float px, py, pz, dx, dy, dz, tr, tg, tb, ar, ag, ab;
+      uint32_t meta = 0;
+      if (have) {
+        const int e = base + tid;
+        px = q.at(0, e); py = q.at(1, e); pz = q.at(2, e);
+        dx = q.at(3, e); dy = q.at(4, e); dz = q.at(5, e);
+        tr = q.at(6, e); tg = q.at(7, e); tb = q.at(8, e);
+        ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e);
+        meta = __float_as_uint(q.at(12, e));
+      }
+      __syncthreads();   // every record of this batch is in registers before slots are reused
+      bool again = false;
+      int idx2 = -1;
+      if (have) {
+        const int lpix = int(meta & 2047u), level = int((meta >> 11) & 127u), idx = int(meta >> 18);
+        const int lx = lpix & (kStripW - 1), ly = lpix >> 6;
+        const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
+        const uint32_t pixel_key = mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(p.sample_index));
+        ++n_shade;
+        float ox, oy, oz;
+        bool cont = shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, mix(pixel_key, uint32_t(level + 1)),
+                                    tr, tg, tb, ar, ag, ab, ox, oy, oz);
+        cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
+        if (cont) {
+          float t;
+          ++n_trace;
+          nearest_hit(sg, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);
+          if (idx2 >= 0) {
+            again = true;
+            px = fmaf(dx, t, ox); py = fmaf(dy, t, oy); pz = fmaf(dz, t, oz);
+            meta = uint32_t(lpix) | (uint32_t(level + 1) << 11) | (uint32_t(idx2) << 18);
+          }
+        }
+        if (!again) {
+          const long long gpix = frame_px + (long long)(row0 + ly) * p.nx + (col0 + lx);
+          finish_pixel(p, gpix, gpix - frame_px + accum_px, ar, ag, ab, &stage[lpix]);
+        }
+      }
+      const int slot = queue_reserve(again, push, base);
+      if (again) {
+        q.at(0, slot) = px; q.at(1, slot) = py; q.at(2, slot) = pz;
+        q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
+        q.at(6, slot) = tr; q.at(7, slot) = tg; q.at(8, slot) = tb;
+        q.at(9, slot) = ar; q.at(10, slot) = ag; q.at(11, slot) = ab;
+        q.at(12, slot) = __uint_as_float(meta);
+      }
+      __syncthreads();
+      q_count = base + int(*push);
+      ++phase;
+    }
+  }
+
+  // ---- ray statistics + packed-RGB store -------------------------------------------------------
+  if (n_trace) atomicAdd(&s_cnt[0], n_trace);
+  if (n_shade) atomicAdd(&s_cnt[1], n_shade);
+  __syncthreads();
+  if (p.out_rgb && p.sample_index + 1 == p.n_samples)
+    store_tile_rgb<kStripW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
+  if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, (unsigned long long)rows * cols);
+}
+
+// ------------------------------------------------------------------------------------------
+// PIXEL KERNEL (rt_set_option(RT_OPT_KERNEL, RT_KERNEL_PIXEL)): one thread per pixel, the whole
+// path in one loop, no compaction.  Same arithmetic as the stream kernel; kept as the baseline
+// for the divergence / active-lane counters (profiles/).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void rt_pixel_kernel(const RenderParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* sg = reinterpret_cast<float4*>(smem);
+  const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
+  uint32_t* stage = reinterpret_cast<uint32_t*>(smem + geom_bytes);            // [8][32]
+  unsigned int* s_cnt = reinterpret_cast<unsigned int*>(stage + kTileW * kTileH);
 
   const int tid = threadIdx.x;
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   if (tid < 2) s_cnt[tid] = 0u;
   __syncthreads();
 
+  const int tiles_x = (p.nx + kTileW - 1) / kTileW, tiles_y = (p.n_rows + kTileH - 1) / kTileH;
+  const int frame = blockIdx.x / (tiles_x * tiles_y);
+  const int tile = blockIdx.x - frame * (tiles_x * tiles_y);
+  const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   const int wave = tid >> 6, lane = tid & 63;
   const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
-  const int col = blockIdx.x * kTileW + lx;   // column inside the window
-  const int lrow = blockIdx.y * kTileH + ly;  // local row
-  const bool active = (col < p.nx) && (lrow < p.n_rows);
+  const int col0 = tile_x * kTileW, row0 = tile_y * kTileH;
+  const int cols = min(kTileW, p.nx - col0), rows = min(kTileH, p.n_rows - row0);
+  const rt_camera& cam = p.cams[frame];
+  const uint32_t seed32 = p.seeds[frame];
+  const long long frame_px = (long long)frame * p.frame_stride_px;
+  const long long accum_px = (long long)frame * p.accum_stride_px;
 
-  float cr = 0.f, cg = 0.f, cb = 0.f;
-  int hit0 = -1;
   uint32_t n_trace = 0, n_shade = 0;
-  if (active) {
-    const int x = p.x0 + col;
-    const int y = row_of(p, lrow);
-    const float fw = float(p.width), fh = float(p.height);
-    const float aspect = fw / fh;                                   // :290
-    for (int sidx = 0; sidx < p.samples; ++sidx) {                  // :292
-      const uint32_t pixel_key = mix(mix(mix(p.seed32, uint32_t(x)), uint32_t(y)), uint32_t(sidx));
-      const uint32_t jk = mix(pixel_key, 0u);
-      const float u = ((float(x) + draw(p.rng_mode, jk, 0u)) / fw) * 2.0f - 1.0f;            // :293
-      const float v = -(((float(y) + draw(p.rng_mode, jk, 1u)) / fh) * 2.0f - 1.0f) / aspect;  // :294
-      float dx = fmaf(p.cam.up[0], v, p.cam.right[0] * u) + p.cam.forward[0];
-      float dy = fmaf(p.cam.up[1], v, p.cam.right[1] * u) + p.cam.forward[1];
-      float dz = fmaf(p.cam.up[2], v, p.cam.right[2] * u) + p.cam.forward[2];
-      const float inv = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));                    // :295
-      dx *= inv; dy *= inv; dz *= inv;
-      float r, g, b;
-      trace_path<kShadowBatch>(p, sg, p.cam.origin[0], p.cam.origin[1], p.cam.origin[2], dx, dy, dz,
-                               pixel_key, r, g, b, hit0, n_trace, n_shade);
-      cr += r; cg += g; cb += b;                                    // :296
+  if (lx < cols && ly < rows) {
+    const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
+    uint32_t pixel_key;
+    float dx, dy, dz;
+    primary_ray<MODE>(p, cam, seed32, x, y, p.sample_index, pixel_key, dx, dy, dz);
+    float ox = cam.origin[0], oy = cam.origin[1], oz = cam.origin[2];
+    float ar = 0.f, ag = 0.f, ab = 0.f, tr = 1.f, tg = 1.f, tb = 1.f;
+    const long long gpix = frame_px + (long long)(row0 + ly) * p.nx + (col0 + lx);
+    for (int level = 0; level <= p.max_depth; ++level) {               // :233
+      float t;
+      int idx;
+      ++n_trace;
+      nearest_hit(sg, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx);
+      if (level == 0 && p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[gpix] = idx;
+      if (idx < 0) break;                                              // :237-238
+      ++n_shade;
+      const float px = fmaf(dx, t, ox), py = fmaf(dy, t, oy), pz = fmaf(dz, t, oz);
+      if (!shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, mix(pixel_key, uint32_t(level + 1)),
+                           tr, tg, tb, ar, ag, ab, ox, oy, oz))
+        break;
     }
-    const float inv_s = 1.0f / float(p.samples);                    // :297
-    cr = fminf(1.0f, fmaxf(0.0f, cr * inv_s));                      // :318 clamp
-    cg = fminf(1.0f, fmaxf(0.0f, cg * inv_s));
-    cb = fminf(1.0f, fmaxf(0.0f, cb * inv_s));
-    const size_t pix = size_t(lrow) * p.nx + col;
-    if (p.out_hit) p.out_hit[pix] = hit0;
-    if (p.out_f32) {                                                // render_chunk (:305)
-      p.out_f32[pix * 3 + 0] = cr; p.out_f32[pix * 3 + 1] = cg; p.out_f32[pix * 3 + 2] = cb;
-    }
+    finish_pixel(p, gpix, gpix - frame_px + accum_px, ar, ag, ab, &stage[ly * kTileW + lx]);
   }
-
-  // ---- ray statistics: one pair of atomics per workgroup, spread over kCounterSlots lines ----
   if (n_trace) atomicAdd(&s_cnt[0], n_trace);
   if (n_shade) atomicAdd(&s_cnt[1], n_shade);
-
-  // ---- packed-RGB store (:325  (image*255).astype(uint8): truncation) -------------------------
-  if (p.out_rgb) {
-    unsigned char* t = s_tile + ly * (kTileW * 3) + lx * 3;
-    t[0] = (unsigned char)(cr * 255.0f);
-    t[1] = (unsigned char)(cg * 255.0f);
-    t[2] = (unsigned char)(cb * 255.0f);
-  }
   __syncthreads();
-  if (p.out_rgb) {
-    const int tile_x = blockIdx.x * kTileW;
-    const int rows_here = min(kTileH, p.n_rows - blockIdx.y * kTileH);
-    const bool full_w = tile_x + kTileW <= p.nx;
-    const bool aligned = ((p.nx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0);
-    if (full_w && aligned) {
-      // 8 rows x 24 dwords; row starts are dword aligned because nx % 4 == 0 and tile_x % 32 == 0
-      if (tid < kTileH * 24) {
-        const int r = tid / 24, w = tid - r * 24;
-        if (r < rows_here) {
-          const unsigned int val = *reinterpret_cast<const unsigned int*>(s_tile + r * (kTileW * 3) + w * 4);
-          const size_t off = (size_t(blockIdx.y * kTileH + r) * p.nx + tile_x) * 3 + size_t(w) * 4;
-          *reinterpret_cast<unsigned int*>(p.out_rgb + off) = val;
-        }
-      }
-    } else {
-      for (int b = tid; b < kTileH * kTileW * 3; b += kBlock) {
-        const int r = b / (kTileW * 3), cbyte = b - r * (kTileW * 3);
-        if (r < rows_here && tile_x * 3 + cbyte < p.nx * 3) {
-          p.out_rgb[(size_t(blockIdx.y * kTileH + r) * p.nx + tile_x) * 3 + cbyte] = s_tile[b];
-        }
-      }
-    }
-  }
-  if (tid == 0 && p.counters) {
-    const unsigned int nt = s_cnt[0], nsd = s_cnt[1];
-    unsigned long long* slot = p.counters + size_t((blockIdx.x + blockIdx.y * 7u) % kCounterSlots) * 8;
-    const int cols_here = min(kTileW, p.nx - int(blockIdx.x) * kTileW);
-    const int rows_all = min(kTileH, p.n_rows - int(blockIdx.y) * kTileH);
-    if (nt) atomicAdd(slot + 0, (unsigned long long)nt);
-    if (nsd) {
-      atomicAdd(slot + 1, (unsigned long long)nsd);
-      atomicAdd(slot + 3, (unsigned long long)nsd * (unsigned long long)(1 + p.L.ns));
-    }
-    atomicAdd(slot + 2, (unsigned long long)cols_here * rows_all * p.samples);
-  }
+  if (p.out_rgb && p.sample_index + 1 == p.n_samples)
+    store_tile_rgb<kTileW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
+  if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, (unsigned long long)rows * cols);
 }
 
 // out[y] = gathered[rank of y][local row of y]  (rt_scatter_rows)
@@ -381,7 +612,10 @@ struct rt_ctx {
   float4* d_mat = nullptr;
   float* d_spec = nullptr;
   unsigned long long* d_counters = nullptr;
+  float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
+  size_t accum_floats = 0;
   int n_spheres = -1;
+  int kernel = RT_KERNEL_STREAM;
   DevLights lights{};
   std::string err;
 };
@@ -405,20 +639,23 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(ctx, RT_EDEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
-size_t lds_bytes(int n_spheres) {
-  return size_t((n_spheres * 16 + 15) / 16) * 16 + kTileH * kTileW * 3 + 16;
+size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
+size_t stream_lds(int n_spheres) {
+  return geom_lds(n_spheres) + size_t(kQueueFields) * kQueueCap * 4 + size_t(kStripPix) * 4 + 32;
 }
+size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
 struct Window {
   int x0, nx, n_rows, tile_rows, tile_first, tile_stride, y0;
 };
 
-int launch(rt_ctx* ctx, const rt_camera* cam, int width, int height, const Window& w, int samples,
-           int max_depth, int rng_mode, uint64_t seed, uint8_t* out_rgb, float* out_f32,
-           int32_t* out_hit) {
+// Validates, then launches ceil(n_frames / 16) x samples kernels on ctx->stream.
+int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames, int width,
+           int height, const Window& w, int samples, int max_depth, int rng_mode, uint8_t* out_rgb,
+           float* out_f32, int32_t* out_hit, long long out_frame_stride_px = 0) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (ctx->n_spheres < 0) return fail(ctx, RT_ESTATE, "rt_upload_scene has not been called");
-  if (!cam) return fail(ctx, RT_EINVAL, "camera is NULL");
+  if (!cams || !seeds) return fail(ctx, RT_EINVAL, "camera/seed is NULL");
   if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20))
     return fail(ctx, RT_EINVAL, "width/height out of range: %dx%d", width, height);
   if (samples < 1 || samples > 65536) return fail(ctx, RT_EINVAL, "samples out of range: %d", samples);
@@ -427,38 +664,95 @@ int launch(rt_ctx* ctx, const rt_camera* cam, int width, int height, const Windo
   if (rng_mode != RT_RNG_CONSTANT && rng_mode != RT_RNG_KEYED)
     return fail(ctx, RT_EINVAL, "unknown rng_mode %d", rng_mode);
   if (!out_rgb && !out_f32 && !out_hit) return fail(ctx, RT_EINVAL, "no output buffer given");
-  for (int i = 0; i < 12; ++i)
-    if (!std::isfinite((&cam->origin[0])[i])) return fail(ctx, RT_EINVAL, "camera has a non-finite value");
-  if (w.n_rows == 0 || w.nx == 0) return RT_OK;  // empty window: nothing to do
+  for (int f = 0; f < n_frames; ++f)
+    for (int i = 0; i < 12; ++i)
+      if (!std::isfinite((&cams[f].origin[0])[i]))
+        return fail(ctx, RT_EINVAL, "camera %d has a non-finite value", f);
   if (w.nx < 0 || w.n_rows < 0) return fail(ctx, RT_EINVAL, "negative window");
+  if (w.n_rows == 0 || w.nx == 0 || n_frames == 0) return RT_OK;  // empty: nothing to do
+  const long long win_px = (long long)w.nx * w.n_rows;
+  if (win_px > (1ll << 31)) return fail(ctx, RT_EINVAL, "window of %lld pixels is too large", win_px);
+  if (out_frame_stride_px != 0 && out_frame_stride_px < win_px)
+    return fail(ctx, RT_EINVAL, "out_frame_stride_px %lld is smaller than a frame (%lld pixels)",
+                out_frame_stride_px, win_px);
+  const long long frame_px = out_frame_stride_px ? out_frame_stride_px : win_px;
+
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  const int batch = std::min(n_frames, kMaxBatch);
+  if (samples > 1) {  // running sums over samples, one slab per frame of a batch
+    const size_t need = size_t(win_px) * 3 * size_t(batch);
+    if (need > ctx->accum_floats) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_accum) RT_HIP(ctx, hipFree(ctx->d_accum));
+      ctx->d_accum = nullptr; ctx->accum_floats = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_accum, need * sizeof(float)));
+      ctx->accum_floats = need;
+    }
+  }
 
   RenderParams p{};
-  p.cam = *cam;
   p.L = ctx->lights;
   p.width = width; p.height = height;
   p.x0 = w.x0; p.nx = w.nx; p.n_rows = w.n_rows;
   p.tile_rows = w.tile_rows; p.tile_first = w.tile_first; p.tile_stride = w.tile_stride; p.y0 = w.y0;
-  p.samples = samples; p.max_depth = max_depth; p.rng_mode = rng_mode;
-  p.seed32 = uint32_t(seed ^ (seed >> 32));
+  p.n_samples = samples; p.max_depth = max_depth;
   p.n_spheres = ctx->n_spheres;
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec;
-  p.out_rgb = out_rgb; p.out_f32 = out_f32; p.out_hit = out_hit;
+  p.accum = ctx->d_accum;
   p.counters = ctx->d_counters;
+  p.frame_stride_px = frame_px;
+  p.accum_stride_px = win_px;
+  const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
+  unsigned per_frame;
+  if (stream_kernel) {
+    p.strips_x = (w.nx + kStripW - 1) / kStripW; p.strips_y = (w.n_rows + kStripH - 1) / kStripH;
+    per_frame = unsigned(p.strips_x) * unsigned(p.strips_y);
+  } else {
+    per_frame = unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH);
+  }
+  const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres) : pixel_lds(ctx->n_spheres);
 
-  const unsigned gx = unsigned((w.nx + kTileW - 1) / kTileW), gy = unsigned((w.n_rows + kTileH - 1) / kTileH);
-  if (gy > 65535u * 16u) return fail(ctx, RT_EINVAL, "too many rows for one launch");
-  RT_HIP(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(rt_render_kernel, dim3(gx, gy, 1), dim3(kBlock), lds_bytes(ctx->n_spheres),
-                     ctx->stream, p);
-  RT_HIP(ctx, hipGetLastError());
+  for (int f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
+    const int nf = std::min(kMaxBatch, n_frames - f0);
+    p.n_frames = nf;
+    for (int f = 0; f < nf; ++f) {
+      p.cams[f] = cams[f0 + f];
+      p.seeds[f] = uint32_t(seeds[f0 + f] ^ (seeds[f0 + f] >> 32));
+    }
+    p.out_rgb = out_rgb ? out_rgb + size_t(f0) * frame_px * 3 : nullptr;
+    p.out_f32 = out_f32 ? out_f32 + size_t(f0) * frame_px * 3 : nullptr;
+    p.out_hit = out_hit ? out_hit + size_t(f0) * frame_px : nullptr;
+    const dim3 grid(per_frame * unsigned(nf), 1, 1);
+    for (int s = 0; s < samples; ++s) {
+      p.sample_index = s;
+      if (stream_kernel) {
+        if (rng_mode == RT_RNG_KEYED)
+          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
+        else
+          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_CONSTANT>, grid, dim3(kBlock), lds, ctx->stream, p);
+      } else {
+        if (rng_mode == RT_RNG_KEYED)
+          hipLaunchKernelGGL(rt_pixel_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
+        else
+          hipLaunchKernelGGL(rt_pixel_kernel<RT_RNG_CONSTANT>, grid, dim3(kBlock), lds, ctx->stream, p);
+      }
+      RT_HIP(ctx, hipGetLastError());
+    }
+  }
   return RT_OK;
+}
+
+template <typename K>
+hipError_t allow_big_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* rt_version(void) { return "rt355 0.1 (gfx950)"; }
+const char* rt_version(void) { return "rt355 0.2 (gfx950)"; }
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
@@ -496,9 +790,11 @@ int rt_create(int device_id, rt_ctx** out) {
     return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * 8)) != hipSuccess)
     return bail(e, "hipMemset");
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(rt_render_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               int(lds_bytes(RT_MAX_SPHERES)))) != hipSuccess)
+  const size_t big = stream_lds(RT_MAX_SPHERES);
+  if ((e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
+      (e = allow_big_lds(rt_stream_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess ||
+      (e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
+      (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
   *out = ctx;
   return RT_OK;
@@ -512,6 +808,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_mat) (void)hipFree(ctx->d_mat);
   if (ctx->d_spec) (void)hipFree(ctx->d_spec);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   delete ctx;
 }
 
@@ -521,6 +818,15 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream, int use_own_stream) {
   // torch.cuda.current_stream().cuda_stream is unless the caller switched streams).
   ctx->stream = use_own_stream ? ctx->own_stream : static_cast<hipStream_t>(hip_stream);
   return RT_OK;
+}
+
+int rt_set_option(rt_ctx* ctx, int option, int value) {
+  if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
+  if (option == RT_OPT_KERNEL && (value == RT_KERNEL_STREAM || value == RT_KERNEL_PIXEL)) {
+    ctx->kernel = value;
+    return RT_OK;
+  }
+  return fail(ctx, RT_EINVAL, "unknown option %d / value %d", option, value);
 }
 
 int rt_synchronize(rt_ctx* ctx) {
@@ -572,29 +878,44 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samp
               int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit) {
   if (!out_rgb) return fail(ctx, RT_EINVAL, "out_rgb is NULL");
   Window w{0, width, height, height > 0 ? height : 1, 0, 1, 0};
-  return launch(ctx, cam, width, height, w, samples, max_depth, rng_mode, seed, out_rgb, nullptr, out_hit);
+  return launch(ctx, cam, &seed, 1, width, height, w, samples, max_depth, rng_mode, out_rgb, nullptr, out_hit);
 }
 
-int rt_render_rows(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
-                   int max_depth, int rng_mode, uint64_t seed, int tile_rows, int tile_first,
-                   int tile_stride, uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out) {
-  if (n_local_rows_out) *n_local_rows_out = 0;
-  if (tile_rows < 1 || tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
-    return fail(ctx, RT_EINVAL, "bad tiling: tile_rows=%d tile_first=%d tile_stride=%d", tile_rows,
-                tile_first, tile_stride);
-  if (width <= 0 || height <= 0) return fail(ctx, RT_EINVAL, "width/height out of range: %dx%d", width, height);
-  // rows owned: tiles t = tile_first + j*tile_stride with t*tile_rows < height
+static int rows_owned(int height, int tile_rows, int tile_first, int tile_stride) {
   long long rows = 0;
   const int n_tiles = (height + tile_rows - 1) / tile_rows;
   for (int t = tile_first; t < n_tiles; t += tile_stride) {
     const int r0 = t * tile_rows;
     rows += (r0 + tile_rows <= height) ? tile_rows : (height - r0);
   }
-  if (n_local_rows_out) *n_local_rows_out = int(rows);
-  if (rows == 0) return RT_OK;
+  return int(rows);
+}
+
+int rt_render_rows(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
+                   int max_depth, int rng_mode, uint64_t seed, int tile_rows, int tile_first,
+                   int tile_stride, uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out) {
+  return rt_render_frames_rows(ctx, cam, &seed, 1, width, height, samples, max_depth, rng_mode, tile_rows,
+                               tile_first, tile_stride, 0, out_rgb, out_hit, n_local_rows_out);
+}
+
+int rt_render_frames_rows(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames,
+                          int width, int height, int samples, int max_depth, int rng_mode,
+                          int tile_rows, int tile_first, int tile_stride, int64_t out_frame_stride_px,
+                          uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out) {
+  if (n_local_rows_out) *n_local_rows_out = 0;
+  if (n_frames < 0) return fail(ctx, RT_EINVAL, "n_frames < 0");
+  if (tile_rows < 1 || tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
+    return fail(ctx, RT_EINVAL, "bad tiling: tile_rows=%d tile_first=%d tile_stride=%d", tile_rows,
+                tile_first, tile_stride);
+  if (width <= 0 || height <= 0) return fail(ctx, RT_EINVAL, "width/height out of range: %dx%d", width, height);
+  const int rows = rows_owned(height, tile_rows, tile_first, tile_stride);
+  if (n_local_rows_out) *n_local_rows_out = rows;
+  if (rows == 0 || n_frames == 0) return RT_OK;
   if (!out_rgb) return fail(ctx, RT_EINVAL, "out_rgb is NULL");
-  Window w{0, width, int(rows), tile_rows, tile_first, tile_stride, 0};
-  return launch(ctx, cam, width, height, w, samples, max_depth, rng_mode, seed, out_rgb, nullptr, out_hit);
+  Window w{0, width, rows, tile_rows, tile_first, tile_stride, 0};
+  if (out_frame_stride_px < 0) return fail(ctx, RT_EINVAL, "negative out_frame_stride_px");
+  return launch(ctx, cams, seeds, n_frames, width, height, w, samples, max_depth, rng_mode, out_rgb, nullptr,
+                out_hit, out_frame_stride_px);
 }
 
 int rt_render_chunk(rt_ctx* ctx, const rt_camera* cam, int x_start, int x_end, int y_start, int y_end,
@@ -608,7 +929,7 @@ int rt_render_chunk(rt_ctx* ctx, const rt_camera* cam, int x_start, int x_end, i
   // the formula), so no clipping against width/height here either.
   Window w{x_start, x_end - x_start, rows, rows > 0 ? rows : 1, 0, 1, y_start};
   if (rows == 0 || x_end == x_start) return RT_OK;
-  return launch(ctx, cam, width, height, w, samples, max_depth, rng_mode, seed, nullptr, out_rgbf, nullptr);
+  return launch(ctx, cam, &seed, 1, width, height, w, samples, max_depth, rng_mode, nullptr, out_rgbf, nullptr);
 }
 
 int rt_render_frames(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames,
@@ -616,26 +937,20 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, 
   if (n_frames < 0) return fail(ctx, RT_EINVAL, "n_frames < 0");
   if (n_frames == 0) return RT_OK;
   if (!cams || !seeds || !out_rgb) return fail(ctx, RT_EINVAL, "cams/seeds/out_rgb is NULL");
-  const size_t frame_bytes = size_t(width) * size_t(height) * 3;
-  for (int f = 0; f < n_frames; ++f) {
-    int rc = rt_render(ctx, &cams[f], width, height, samples, max_depth, rng_mode, seeds[f],
-                       out_rgb + frame_bytes * f, nullptr);
-    if (rc != RT_OK) return rc;
-  }
-  return RT_OK;
+  Window w{0, width, height, height > 0 ? height : 1, 0, 1, 0};
+  return launch(ctx, cams, seeds, n_frames, width, height, w, samples, max_depth, rng_mode, out_rgb, nullptr,
+                nullptr);
 }
 
 int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_bytes, int n_ranks,
                     int width, int height, int tile_rows, uint8_t* out_rgb) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (!gathered || !out_rgb) return fail(ctx, RT_EINVAL, "gathered/out_rgb is NULL");
-  if (n_ranks < 1 || width <= 0 || height <= 0 || tile_rows < 1 || height > 65535 * 16)
+  if (n_ranks < 1 || width <= 0 || height <= 0 || tile_rows < 1 || height > 65535)
     return fail(ctx, RT_EINVAL, "bad scatter arguments");
   // every rank's slab must hold its rows
-  const int n_tiles = (height + tile_rows - 1) / tile_rows;
-  const long long max_rows = (long long)((n_tiles + n_ranks - 1) / n_ranks) * tile_rows;
-  if (rank_stride_bytes < 0 || (n_ranks > 1 && rank_stride_bytes < max_rows * width * 3 &&
-                                rank_stride_bytes < (long long)height * width * 3))
+  const long long max_rows = rows_owned(height, tile_rows, 0, n_ranks);
+  if (rank_stride_bytes < 0 || (n_ranks > 1 && rank_stride_bytes < max_rows * width * 3))
     return fail(ctx, RT_EINVAL, "rank_stride_bytes %lld too small", (long long)rank_stride_bytes);
   const long long row_bytes = (long long)width * 3;
   const int vec4 = (row_bytes % 4 == 0) && (rank_stride_bytes % 4 == 0) &&

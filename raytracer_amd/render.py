@@ -138,23 +138,43 @@ class Renderer:
         return out
 
     def render_frames(self, cameras, seeds, width, height, samples=1, *,
-                      max_depth=_DEFAULT_MAX_DEPTH, rng_mode="keyed", out=None):
-        """Animation batch -> uint8 [F, H, W, 3]."""
+                      max_depth=_DEFAULT_MAX_DEPTH, rng_mode="keyed", out=None,
+                      tile_rows=None, tile_first=0, tile_stride=1):
+        """Animation batch -> uint8 [F, H, W, 3]; up to 16 frames share one kernel launch.
+
+        With ``tile_rows`` the batch holds only this rank's row tiles of every frame
+        (-> uint8 [F, local_rows, W, 3], rt_render_frames_rows)."""
         torch = _torch()
+        from .tiling import local_row_count
         width, height = _dims(width, height)
         n = len(cameras)
         if len(seeds) != n:
             raise ValueError("one seed per camera")
+        if tile_rows is None:
+            tile_rows, tile_first, tile_stride = max(height, 1), 0, 1
+        rows = local_row_count(height, tile_rows, tile_first, tile_stride) if height else 0
         if out is None:
-            out = self._alloc((n, height, width, 3), torch.uint8)
-        _check_out(out, (n, height, width, 3), torch.uint8, self.device)
+            out = self._alloc((n, rows, width, 3), torch.uint8)
+        # `out` may hold more rows per frame than this rank owns (equal slabs for the gather)
+        if out.dim() != 4 or out.shape[0] != n or out.shape[1] < rows:
+            raise ValueError(f"out must be [n_frames, >= {rows}, {width}, 3]")
+        _check_out(out, (n, out.shape[1], width, 3), torch.uint8, self.device)
+        stride_px = out.shape[1] * width
         cams = (RtCamera * max(n, 1))(*[RtCamera.from_camera(c) for c in cameras])
         sd = (ctypes.c_uint64 * max(n, 1))(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds])
-        if n and width * height:
-            self._check(self._L.rt_render_frames(self._h, cams, sd, n, width, height, int(samples),
-                                                 int(max_depth), _lib.RNG_MODES[rng_mode],
-                                                 out.data_ptr()))
-        return out
+        if n and width * rows:
+            nrows = ctypes.c_int(0)
+            self._check(self._L.rt_render_frames_rows(
+                self._h, cams, sd, n, width, height, int(samples), int(max_depth),
+                _lib.RNG_MODES[rng_mode], int(tile_rows), int(tile_first), int(tile_stride),
+                stride_px, out.data_ptr(), None, ctypes.byref(nrows)))
+            assert nrows.value == rows
+        return out[:, :rows]
+
+    def set_kernel(self, name: str):
+        """'stream' (default: LDS work-queue kernel) or 'pixel' (one thread per pixel baseline)."""
+        v = {"stream": _lib.RT_KERNEL_STREAM, "pixel": _lib.RT_KERNEL_PIXEL}[name]
+        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_KERNEL, v))
 
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
