@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_MAX_SPHERES 4096      /* 16 B of LDS per sphere -> 64 KiB at the limit            */
+#define RT_MAX_SPHERES 2048      /* 32 B of LDS per sphere (geometry + camera table): 64 KiB   */
 #define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
 #define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
 
@@ -153,6 +153,10 @@ int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_by
  * find_nearest_intersection-equivalent scan (raytracer.py:152-172), SURVEY.md §8d. */
 int rt_get_ray_counts(rt_ctx* ctx, uint64_t out[4]);
 int rt_reset_ray_counts(rt_ctx* ctx);
+
+/* Raw counter words summed over slots (diagnostics): [0..3] as rt_get_ray_counts' inputs, [8..15]
+ * per-phase s_memtime sums of the stream kernel, non-zero only in a -DRT_STAMPS=1 build. */
+int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]);
 
 /* Build/ABI information. */
 const char* rt_version(void);

@@ -7,7 +7,8 @@ import os
 
 from .scenes import RtCamera, RtLights
 
-_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librt355.so")
+_SO = os.environ.get("RT355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                   "librt355.so")   # RT355_LIB: A/B builds only
 _lib = None
 
 RT_RNG_CONSTANT, RT_RNG_KEYED = 0, 1
@@ -19,7 +20,7 @@ RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT:
 SYMBOLS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize",
            "rt_set_option", "rt_upload_scene", "rt_render", "rt_render_rows", "rt_render_frames_rows",
            "rt_render_chunk", "rt_render_frames",
-           "rt_scatter_rows", "rt_get_ray_counts", "rt_reset_ray_counts", "rt_version")
+           "rt_scatter_rows", "rt_get_ray_counts", "rt_reset_ray_counts", "rt_debug_counters", "rt_version")
 
 
 class RtError(RuntimeError):
@@ -69,6 +70,7 @@ def load():
                                   c_void_p]
     L.rt_get_ray_counts.argtypes = [c_void_p, P(c_u64)]
     L.rt_reset_ray_counts.argtypes = [c_void_p]
+    L.rt_debug_counters.argtypes = [c_void_p, P(c_u64)]
     L.rt_version.argtypes = []; L.rt_version.restype = ctypes.c_char_p
     for name in SYMBOLS:
         if name not in ("rt_destroy", "rt_last_error", "rt_version"):

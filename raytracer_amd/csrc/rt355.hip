@@ -23,6 +23,22 @@
 
 #include "../../include/rt355.h"
 
+#ifndef RT_ACC_BITS
+#define RT_ACC_BITS 1     // shadow verdicts accumulated with sign-bit and/or (1) or min/max (0)
+#endif
+#ifndef RT_NEAR_SRC
+#define RT_NEAR_SRC 2     // reflection-ray scan reads spheres from: 0 LDS, 2 scalar loads
+#endif
+#ifndef RT_STAMPS
+#define RT_STAMPS 0       // diagnostic build: per-phase s_memtime sums into counters[.][8..15]
+#endif
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4   // __launch_bounds__ occupancy target: caps VGPRs at 512/4 = 128
+#endif
+#ifndef RT_GEOM_SRC
+#define RT_GEOM_SRC 0     // shadow scan reads spheres from: 0 LDS, 1 LDS prefetched, 2 scalar loads
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -35,6 +51,7 @@ struct DevLights {
 };
 
 constexpr int kMaxBatch = 16;  // frames per launch
+struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
 
 struct RenderParams {
   DevLights L;
@@ -50,6 +67,7 @@ struct RenderParams {
   const float4* geom;    // cx cy cz r^2
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
+  const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
   uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
   float* out_f32;        // [frame][n_rows][nx][3] or null (render_chunk)
   int32_t* out_hit;      // [frame][n_rows][nx] or null
@@ -63,6 +81,12 @@ struct RenderParams {
 
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 cache lines
+constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shadow | 8.. phase stamps
+#if RT_STAMPS
+#define RT_NOW() ((unsigned long long)clock64())
+#else
+#define RT_NOW() 0ull
+#endif
 constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (raytracer.py:80)
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
@@ -86,6 +110,23 @@ __device__ __forceinline__ float draw(uint32_t level_key, uint32_t i) {
   return float(fmix32(level_key + i * 0x9E3779B9u + 0x7F4A7C15u) >> 8) * (1.0f / 16777216.0f);
 }
 
+// 1-ulp hardware reciprocal / reciprocal square root / square root (v_rcp_f32, v_rsq_f32,
+// v_sqrt_f32: quarter-rate single instructions) instead of the ~10-25 instruction IEEE expansions;
+// the FP64 reference is ~1e-7 away either way.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// wave-uniform reads of the constant sphere tables: address space 4 makes hipcc emit scalar loads
+// (s_load_dwordx4..x16 into SGPRs) — no LDS traffic, no VGPRs, and SGPR operands feed the VALU
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const float4 __attribute__((address_space(4))) * cgeom_t;
+__device__ __forceinline__ cgeom_t as_const(const float4* p) { return (cgeom_t)(unsigned long long)(p); }
+#else   // host pass only parses the kernels
+typedef const float4* cgeom_t;
+__device__ __forceinline__ cgeom_t as_const(const float4* p) { return p; }
+#endif
+
 __device__ __forceinline__ float pow50(float x) {  // `** 50` (raytracer.py:193,208), x >= 0
   float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16;
   return x32 * x16 * x2;
@@ -108,27 +149,129 @@ __device__ __forceinline__ int row_of(const RenderParams& p, int lr) {
 // the error at ~|l| * ulp(|co|).  Strict `<` in index order keeps the lowest index on ties, and
 // t == 0 / t < 0 are rejected as the reference's `if t and ...` does (raytracer.py:102,162).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, int n, float ox, float oy,
-                                            float oz, float dx, float dy, float dz, float& best_t,
-                                            int& best_i) {
-  const float inv_a = 1.0f / fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // :95, computed, not assumed 1
+__device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const float4* __restrict__ gg,
+                                            int n, float ox, float oy, float oz, float dx, float dy,
+                                            float dz, float& best_t, int& best_i) {
+  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // :95, computed, not assumed 1
   best_t = INFINITY;
   best_i = -1;
+#if RT_NEAR_SRC == 2
+  cgeom_t src = as_const(gg);
+#else
+  const float4* src = sg;   // wave-uniform address: LDS broadcast read
+#endif
 #pragma unroll 4
   for (int i = 0; i < n; ++i) {
-    const float4 s = sg[i];  // wave-uniform address: LDS broadcast read
+    const float4 s = src[i];
     const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
     const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
     const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
     const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));  // r^2 - |l|^2
     if (dl >= 0.0f) {
-      const float t = q - sqrtf(dl * inv_a);
+      const float t = q - fsqrt(dl * inv_a);
       if (t > 0.0f && t < best_t) {
         best_t = t;
         best_i = i;
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Primary rays (render_pixel :295-296 -> trace_ray -> find_nearest_intersection): every ray of a
+// frame starts at the camera, so co = C - O and c = |co|^2 - r^2 are the same for all lanes.  The
+// workgroup computes them once per sphere (c in FP64, spheres that contain the camera get c = +inf:
+// their near root is negative, :102) into LDS, and a test is  nb = co.D, disc' = nb^2 - c  — 4 VALU
+// ops.  Candidates (disc' >= 0, nb > 0) of four spheres are detected with one sign-bit test so the
+// root is only evaluated where some lane needs it.  D is a unit vector here (a = 1 +- 2e-7).  The
+// plain b^2-4ac form is good enough to CHOOSE the sphere (its error, ~|co|^2 * 1e-7, moves a
+// silhouette by < 1 % of a pixel and is far inside the grazing-tie margin); the hit distance of
+// the chosen sphere is then recomputed once in the cancellation-free form of nearest_hit.
+// ------------------------------------------------------------------------------------------
+// table entry: four spheres, struct-of-arrays, so one s_load_dwordx16 brings a group and packed
+// VALU ops find sphere pairs in adjacent SGPRs.  w holds -c (or -inf where the camera is inside).
+struct __attribute__((aligned(64))) CamGroup {
+  float x[4], y[4], z[4], negc[4];
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const CamGroup __attribute__((address_space(4))) * camtab_t;
+__device__ __forceinline__ camtab_t as_const(const CamGroup* p) { return (camtab_t)(unsigned long long)(p); }
+#else
+typedef const CamGroup* camtab_t;
+__device__ __forceinline__ camtab_t as_const(const CamGroup* p) { return p; }
+#endif
+
+__device__ __forceinline__ void primary_hit(const float4* __restrict__ sg, const CamGroup* __restrict__ camtab,
+                                            int n, float ox, float oy, float oz, float dx, float dy,
+                                            float dz, float& best_t, int& best_i) {
+  best_t = INFINITY;
+  best_i = -1;
+  const int ngroups = (n + 3) >> 2;   // the table is padded with never-hit entries
+  camtab_t tab = as_const(camtab);
+  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  if (ngroups == 0) return;
+  CamGroup cur = tab[0];
+  for (int g = 0; g < ngroups; ++g) {
+    // the next group's scalar load is issued before this group's arithmetic and its (rare)
+    // candidate branch, so its latency is covered instead of being paid once per group
+    const CamGroup nxt = tab[g + 1 < ngroups ? g + 1 : g];
+    float nb[4], disc[4];
+    uint32_t any = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      nb[j] = fmaf(cur.z[j], dz, fmaf(cur.y[j], dy, cur.x[j] * dx));
+      disc[j] = fmaf(nb[j], nb[j], cur.negc[j]);
+      any &= __float_as_uint(disc[j]) | __float_as_uint(nb[j]);
+    }
+    if (int(any) >= 0) {
+      // some lane may hit one of these four spheres: decide and measure with the cancellation-free
+      // form of nearest_hit (the table's c carries a safety margin, so this is a superset)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (disc[j] >= 0.0f && nb[j] > 0.0f) {
+          const float4 s = sg[min(4 * g + j, n - 1)];
+          const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+          const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
+          const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
+          const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));
+          const float t = q - fsqrt(dl * inv_a);
+          if (dl >= 0.0f && t > 0.0f && t < best_t) {
+            best_t = t;
+            best_i = 4 * g + j;
+          }
+        }
+      }
+    }
+    cur = nxt;
+  }
+}
+
+// Per-frame table for primary_hit (one tiny launch per batch, ahead of the render kernel on the
+// same stream): per sphere C - O and -(c - margin), c = |C - O|^2 - r^2 in FP64.  The margin
+// (2^-17 |C - O|^2, ~30x the FP32 error of nb^2 - c) makes the cheap test a superset of the exact
+// one; spheres that contain the camera can never be hit from it (near root < 0, :102) -> -inf.
+struct CamBatch {
+  float origin[kMaxBatch][3];
+};
+__global__ __launch_bounds__(256) void rt_camera_table_kernel(const float4* __restrict__ geom, int n,
+                                                              const CamBatch cb,
+                                                              CamGroup* __restrict__ camtab, int n_frames) {
+  const int n4 = (n + 3) & ~3;
+  const int frame = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4 || frame >= n_frames) return;
+  float ex = 0.f, ey = 0.f, ez = 0.f, ew = -INFINITY;
+  if (i < n) {
+    const float4 g = geom[i];
+    const double cx = double(g.x) - double(cb.origin[frame][0]), cy = double(g.y) - double(cb.origin[frame][1]),
+                 cz = double(g.z) - double(cb.origin[frame][2]);
+    const double d2 = cx * cx + cy * cy + cz * cz;
+    const double c = d2 - double(g.w);
+    ex = float(cx); ey = float(cy); ez = float(cz);
+    ew = c > 0.0 ? -float(c - d2 * (1.0 / 131072.0)) : -INFINITY;
+  }
+  CamGroup& grp = camtab[size_t(frame) * (n4 >> 2) + (i >> 2)];
+  grp.x[i & 3] = ex; grp.y[i & 3] = ey; grp.z[i & 3] = ez; grp.negc[i & 3] = ew;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -145,7 +288,8 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, int n
 // to second order.
 // ------------------------------------------------------------------------------------------
 template <int MODE, int B>
-__device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg, int n,
+__device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg,
+                                         const float4* __restrict__ gg, int n,
                                          float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          float mr, float mg, float mb, float spec, uint32_t level_key,
@@ -172,13 +316,15 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
       lx -= px; ly -= py; lz -= pz;                        // :183 / :198
       // a ray beyond the light's sample count gets L = 0: it can never be shadowed and every
       // weight below (N.L, V.R) is then 0 too
-      const float inv = (j < nrays) ? 1.0f / sqrtf(fmaf(lz, lz, fmaf(ly, ly, lx * lx))) : 0.0f;
+      const float inv = (j < nrays) ? frsq(fmaf(lz, lz, fmaf(ly, ly, lx * lx))) : 0.0f;
       Lx[k] = lx * inv; Ly[k] = ly * inv; Lz[k] = lz * inv;
-      m[k] = -1.0f;
+      m[k] = -1.0f;   // sign bit set = "no sphere hit yet" in both accumulation forms
     }
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-      const float4 g = sg[i];
+    // One sphere against the B rays.  Verdict accumulation: with RT_ACC_BITS the sign bits do the
+    // work at full VALU rate — hit <=> sign(dl) == 0 and sign(nb) == 0, so `acc &= (dl | nb)`
+    // clears acc's sign bit as soon as any sphere is hit (v_min/v_max/v_cmp are half rate on
+    // gfx950, v_and/v_or full rate: profiles/r1_ubench_valu_rate.txt).
+    auto test_sphere = [&](const float4 g) {
       const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
       const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
       const float r2 = (c > 0.0f) ? g.w : -INFINITY;
@@ -187,16 +333,48 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
         const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
         const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
         const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
+#if RT_ACC_BITS
+        m[k] = __uint_as_float(__float_as_uint(m[k]) & (__float_as_uint(dl) | __float_as_uint(nb)));
+        asm volatile("" : "+v"(m[k]));   // keep the and-chain sequential (no reassociation tree)
+#else
         m[k] = __builtin_fmaxf(m[k], __builtin_fminf(dl, nb));
+#endif
       }
+    };
+#if RT_GEOM_SRC == 1
+    // LDS broadcast reads, software-pipelined one pair of spheres ahead so the ds_read latency is
+    // covered by the previous pair's 26 ray tests
+    {
+      float4 g0 = sg[0], g1 = sg[n > 1 ? 1 : 0];
+      int i = 0;
+      for (; i + 2 < n; i += 2) {
+        const float4 h0 = sg[i + 2], h1 = sg[i + 3 < n ? i + 3 : i + 2];
+        test_sphere(g0);
+        test_sphere(g1);
+        g0 = h0; g1 = h1;
+      }
+      if (i < n) test_sphere(g0);
+      if (i + 1 < n) test_sphere(g1);
     }
+#elif RT_GEOM_SRC == 2
+    // wave-uniform scalar loads straight from the (constant, L2/K$-resident) geometry buffer: the
+    // sphere lives in SGPRs, no LDS traffic and no VGPRs for it
+    {
+      cgeom_t cg = as_const(gg);
+#pragma unroll 2
+      for (int i = 0; i < n; ++i) test_sphere(cg[i]);
+    }
+#else
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) test_sphere(sg[i]);
+#endif
 #pragma unroll
     for (int k = 0; k < B; ++k) {
       const float ndl = fmaf(nz, Lz[k], fmaf(ny, Ly[k], nx * Lx[k]));
       // view . (L - N*(2 L.N))  (:192-193 / :207-208; the sign of R is the reference's)
       const float vdl = -(fmaf(dz, Lz[k], fmaf(dy, Ly[k], dx * Lx[k])));
       const float vr = fmaf(-2.0f * ndl, vdn, vdl);
-      const bool lit = m[k] < 0.0f;                                  // :187 / :202
+      const bool lit = int(__float_as_uint(m[k])) < 0;               // :187 / :202
       const float wd = lit ? fmaxf(0.f, ndl) : 0.f;                  // :188 / :203
       const float ws = lit ? pow50(fmaxf(0.f, vr)) : 0.f;            // :193 / :208
       if (k == 0) {
@@ -230,13 +408,13 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   const float spec = p.spec[idx];
   float nx = px - s.x, ny = py - s.y, nz = pz - s.z;               // :139-140
   {
-    const float inv = 1.0f / sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+    const float inv = frsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
     nx *= inv; ny *= inv; nz *= inv;
   }
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
   float lr, lg, lb;
-  lighting<MODE, kShadowBatch>(p.L, sg, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+  lighting<MODE, kShadowBatch>(p.L, sg, p.geom, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                m.x, m.y, m.z, spec, level_key, lr, lg, lb);
   const float refl = m.w;
   const float keep = 1.0f - refl;                                    // :249
@@ -256,16 +434,19 @@ template <int MODE>
 __device__ __forceinline__ void primary_ray(const RenderParams& p, const rt_camera& cam, uint32_t seed32,
                                             int x, int y, int sidx, uint32_t& pixel_key, float& dx,
                                             float& dy, float& dz) {
+  // (x + r) / W and (y + r) / H stay true divisions: with a reciprocal multiply the centre column of
+  // an odd-width frame is no longer exactly u = 0, and mirror-to-mirror paths amplify that 3e-8 by
+  // ~10x per bounce (tests: facing mirrors).  1/aspect is applied as a multiply.
   const float fw = float(p.width), fh = float(p.height);
-  const float aspect = fw / fh;                                                               // :290
+  const float inv_aspect = fh / fw;                                                           // :290
   pixel_key = mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(sidx));
   const uint32_t jk = mix(pixel_key, 0u);
   const float u = ((float(x) + draw<MODE>(jk, 0u)) / fw) * 2.0f - 1.0f;                       // :293
-  const float v = -(((float(y) + draw<MODE>(jk, 1u)) / fh) * 2.0f - 1.0f) / aspect;           // :294
+  const float v = -(((float(y) + draw<MODE>(jk, 1u)) / fh) * 2.0f - 1.0f) * inv_aspect;       // :294
   dx = fmaf(cam.up[0], v, cam.right[0] * u) + cam.forward[0];
   dy = fmaf(cam.up[1], v, cam.right[1] * u) + cam.forward[1];
   dz = fmaf(cam.up[2], v, cam.right[2] * u) + cam.forward[2];
-  const float inv = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));                         // :295
+  const float inv = frsq(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));                                // :295
   dx *= inv; dy *= inv; dz *= inv;
 }
 
@@ -296,7 +477,7 @@ __device__ __forceinline__ void finish_pixel(const RenderParams& p, long long gp
 __device__ __forceinline__ void flush_counters(const RenderParams& p, unsigned int* s_cnt, unsigned slot_id,
                                                unsigned long long primaries) {
   const unsigned int nt = s_cnt[0], nsd = s_cnt[1];
-  unsigned long long* slot = p.counters + size_t(slot_id % kCounterSlots) * 8;
+  unsigned long long* slot = p.counters + size_t(slot_id % kCounterSlots) * kCounterWords;
   if (nt) atomicAdd(slot + 0, (unsigned long long)nt);
   if (nsd) {
     atomicAdd(slot + 1, (unsigned long long)nsd);
@@ -367,7 +548,7 @@ __device__ __forceinline__ int queue_reserve(bool want, unsigned int* s_push, in
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p) {
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);
   const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
@@ -392,9 +573,12 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
   const uint32_t seed32 = p.seeds[frame];
   const long long frame_px = (long long)frame * p.frame_stride_px;
   const long long accum_px = (long long)frame * p.accum_stride_px;
+  const CamGroup* camtab = p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2);
   __syncthreads();
 
   uint32_t n_trace = 0, n_shade = 0;
+  unsigned long long st_fill = 0, st_fbar = 0, st_pop = 0, st_light = 0, st_near = 0, st_sbar = 0;
+  const unsigned long long st_begin = RT_NOW();
   int q_count = 0;   // uniform across the workgroup
   int fill = 0;      // next group of 4 tiles
   int phase = 0;     // selects the rotating push counter
@@ -403,6 +587,7 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
   for (;;) {
     // ------------------------------ fill -------------------------------------------------
     while (q_count < kBlock && fill < kFillSteps) {
+      const unsigned long long s0 = RT_NOW();
       unsigned int* push = s_push + (phase % 3);
       if (tid == 0) s_push[(phase + 1) % 3] = 0u;
       const int tile = fill * 4 + wave;
@@ -417,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
         primary_ray<MODE>(p, cam, seed32, x, y, p.sample_index, pixel_key, dx, dy, dz);
         float t;
         ++n_trace;
-        nearest_hit(sg, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+        primary_hit(sg, camtab, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
         hit = idx >= 0;
         const long long gpix = frame_px + (long long)(row0 + ly) * p.nx + (col0 + lx);
         if (p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[gpix] = idx;
@@ -437,7 +622,9 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
         // meta: local pixel (11 bits) | level (7 bits) | sphere index (13 bits)
         q.at(12, slot) = __uint_as_float(uint32_t(ly * kStripW + lx) | (0u << 11) | (uint32_t(idx) << 18));
       }
+      const unsigned long long s1 = RT_NOW();
       __syncthreads();
+      st_fill += s1 - s0; st_fbar += RT_NOW() - s1;
       q_count += int(*push);
       ++fill;
       ++phase;
@@ -446,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
 
     // ------------------------------ shade ------------------------------------------------
     {
+      const unsigned long long s0 = RT_NOW();
       unsigned int* push = s_push + (phase % 3);
       if (tid == 0) s_push[(phase + 1) % 3] = 0u;
       const int n_pop = min(kBlock, q_count);
@@ -462,6 +650,8 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
         meta = __float_as_uint(q.at(12, e));
       }
       __syncthreads();   // every record of this batch is in registers before slots are reused
+      const unsigned long long s1 = RT_NOW();
+      unsigned long long s2 = s1;
       bool again = false;
       int idx2 = -1;
       if (have) {
@@ -474,10 +664,11 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
         bool cont = shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, mix(pixel_key, uint32_t(level + 1)),
                                     tr, tg, tb, ar, ag, ab, ox, oy, oz);
         cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
+        s2 = RT_NOW();
         if (cont) {
           float t;
           ++n_trace;
-          nearest_hit(sg, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);
+          nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);
           if (idx2 >= 0) {
             again = true;
             px = fmaf(dx, t, ox); py = fmaf(dy, t, oy); pz = fmaf(dz, t, oz);
@@ -497,7 +688,9 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
         q.at(9, slot) = ar; q.at(10, slot) = ag; q.at(11, slot) = ab;
         q.at(12, slot) = __uint_as_float(meta);
       }
+      const unsigned long long s3 = RT_NOW();
       __syncthreads();
+      st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2; st_sbar += RT_NOW() - s3;
       q_count = base + int(*push);
       ++phase;
     }
@@ -510,6 +703,14 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
   if (p.out_rgb && p.sample_index + 1 == p.n_samples)
     store_tile_rgb<kStripW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
   if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, (unsigned long long)rows * cols);
+#if RT_STAMPS
+  if (lane == 0 && p.counters) {   // per-wave phase sums (diagnostic build only; read by tools/stamps.py)
+    unsigned long long* slot = p.counters + size_t(blockIdx.x % kCounterSlots) * kCounterWords + 8;
+    atomicAdd(slot + 0, st_fill); atomicAdd(slot + 1, st_fbar); atomicAdd(slot + 2, st_pop);
+    atomicAdd(slot + 3, st_light); atomicAdd(slot + 4, st_near); atomicAdd(slot + 5, st_sbar);
+    atomicAdd(slot + 6, RT_NOW() - st_begin); atomicAdd(slot + 7, 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -518,7 +719,7 @@ __global__ __launch_bounds__(kBlock) void rt_stream_kernel(const RenderParams p)
 // for the divergence / active-lane counters (profiles/).
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void rt_pixel_kernel(const RenderParams p) {
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_pixel_kernel(const RenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);
   const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
@@ -556,7 +757,11 @@ __global__ __launch_bounds__(kBlock) void rt_pixel_kernel(const RenderParams p) 
       float t;
       int idx;
       ++n_trace;
-      nearest_hit(sg, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx);
+      if (level == 0)
+        primary_hit(sg, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, ox, oy, oz, dx, dy,
+                    dz, t, idx);
+      else
+        nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx);
       if (level == 0 && p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[gpix] = idx;
       if (idx < 0) break;                                              // :237-238
       ++n_shade;
@@ -612,6 +817,7 @@ struct rt_ctx {
   float4* d_mat = nullptr;
   float* d_spec = nullptr;
   unsigned long long* d_counters = nullptr;
+  CamGroup* d_camtab = nullptr;  // [kMaxBatch][RT_MAX_SPHERES / 4] primary-ray tables
   float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
   size_t accum_floats = 0;
   int n_spheres = -1;
@@ -699,6 +905,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.n_spheres = ctx->n_spheres;
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec;
   p.accum = ctx->d_accum;
+  p.camtab = ctx->d_camtab;
   p.counters = ctx->d_counters;
   p.frame_stride_px = frame_px;
   p.accum_stride_px = win_px;
@@ -723,6 +930,16 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     p.out_f32 = out_f32 ? out_f32 + size_t(f0) * frame_px * 3 : nullptr;
     p.out_hit = out_hit ? out_hit + size_t(f0) * frame_px : nullptr;
     const dim3 grid(per_frame * unsigned(nf), 1, 1);
+    {  // primary-ray tables of this batch (stream order protects the previous batch's readers)
+      CamBatch cb;
+      for (int f = 0; f < nf; ++f) memcpy(cb.origin[f], cams[f0 + f].origin, sizeof cb.origin[f]);
+      const int n4 = (ctx->n_spheres + 3) & ~3;
+      if (n4 > 0) {
+        hipLaunchKernelGGL(rt_camera_table_kernel, dim3(unsigned((n4 + 255) / 256), unsigned(nf), 1), dim3(256),
+                           0, ctx->stream, (const float4*)ctx->d_geom, ctx->n_spheres, cb, ctx->d_camtab, nf);
+        RT_HIP(ctx, hipGetLastError());
+      }
+    }
     for (int s = 0; s < samples; ++s) {
       p.sample_index = s;
       if (stream_kernel) {
@@ -786,9 +1003,11 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_geom, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_mat, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * kCounterSlots * 8)) != hipSuccess)
+  if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * (RT_MAX_SPHERES / 4) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
-  if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * 8)) != hipSuccess)
+  if ((e = hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
+    return bail(e, "hipMalloc");
+  if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMemset");
   const size_t big = stream_lds(RT_MAX_SPHERES);
   if ((e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
@@ -808,6 +1027,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_mat) (void)hipFree(ctx->d_mat);
   if (ctx->d_spec) (void)hipFree(ctx->d_spec);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   delete ctx;
 }
@@ -966,13 +1186,14 @@ int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_by
 
 int rt_get_ray_counts(rt_ctx* ctx, uint64_t out[4]) {
   if (!ctx || !out) return fail(ctx, RT_EINVAL, "ctx/out is NULL");
-  unsigned long long host[kCounterSlots * 8];
+  unsigned long long host[kCounterSlots * kCounterWords];
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RT_HIP(ctx, hipMemcpy(host, ctx->d_counters, sizeof host, hipMemcpyDeviceToHost));
   unsigned long long trace = 0, shade = 0, primary = 0, shadow = 0;
   for (int s = 0; s < kCounterSlots; ++s) {
-    trace += host[s * 8]; shade += host[s * 8 + 1]; primary += host[s * 8 + 2]; shadow += host[s * 8 + 3];
+    const unsigned long long* h = host + s * kCounterWords;
+    trace += h[0]; shade += h[1]; primary += h[2]; shadow += h[3];
   }
   out[0] = primary;
   out[1] = trace - primary;
@@ -981,10 +1202,23 @@ int rt_get_ray_counts(rt_ctx* ctx, uint64_t out[4]) {
   return RT_OK;
 }
 
+int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]) {
+  if (!ctx || !out) return fail(ctx, RT_EINVAL, "ctx/out is NULL");
+  unsigned long long host[kCounterSlots * kCounterWords];
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipMemcpy(host, ctx->d_counters, sizeof host, hipMemcpyDeviceToHost));
+  for (int k = 0; k < kCounterWords; ++k) {
+    out[k] = 0;
+    for (int s = 0; s < kCounterSlots; ++s) out[k] += host[s * kCounterWords + k];
+  }
+  return RT_OK;
+}
+
 int rt_reset_ray_counts(rt_ctx* ctx) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * 8, ctx->stream));
+  RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords, ctx->stream));
   return RT_OK;
 }
 

@@ -29,7 +29,7 @@ __all__ = [
     "MAX_SPHERES", "MAX_AREA_SAMPLES",
 ]
 
-MAX_SPHERES = 4096        # rt355.h RT_MAX_SPHERES (LDS: 16 B geometry per sphere)
+MAX_SPHERES = 2048        # rt355.h RT_MAX_SPHERES (LDS: 32 B per sphere)
 MAX_AREA_SAMPLES = 64     # rt355.h RT_MAX_AREA_SAMPLES
 
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of library builds on the GPU box: tools/ab.sh "<workloads>" lib1.so lib2.so ...
+wls=$1; shift
+for lib in "$@"; do
+  for wl in $wls; do
+    RT355_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --workload $wl 2>&1 | tail -1 | python -c "
+import sys, json
+l=sys.stdin.read().strip()
+try:
+    d=json.loads(l); print('$lib', '$wl', 'Mrays/s', round(d['value']), 'kern_ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],4))
+except Exception as e: print('$lib $wl ERR', l[-300:])
+"
+  done
+done

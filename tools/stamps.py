@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the stream kernel from a -DRT_STAMPS=1 build (diagnostic; never quote its
+run time).  RT355_LIB=<stamps build> python tools/stamps.py [workload] [frames]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from raytracer_amd.render import Renderer
+from raytracer_amd.scenes import Camera
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "t64"
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
+r = Renderer(0)
+r.upload_scene(bench.build_scene(wl))
+for it in range(2):
+    r.reset_ray_counts()
+    r.render_frames([Camera()] * F, range(F), w, h, 1, max_depth=D)
+a = (ctypes.c_uint64 * 16)()
+r._check(r._L.rt_debug_counters(r._h, a))
+names = ["fill work", "fill barrier", "pop+barrier", "lighting", "reflect scan+push", "shade barrier"]
+tot = a[14]
+print(f"{desc}: {a[15]} waves, mean wave lifetime {tot / max(a[15], 1):.0f} clk")
+for i, nm in enumerate(names):
+    print(f"  {nm:20s} {100.0 * a[8 + i] / max(tot, 1):6.2f} %")
+print(f"  {'other (setup/store)':20s} {100.0 * (tot - sum(a[8:14])) / max(tot, 1):6.2f} %")
