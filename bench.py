@@ -13,10 +13,10 @@ total work per step is fixed => "strong" scaling.  Rays are counted by the kerne
 (rt_get_ray_counts), not modelled.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — FP32-VALU roofline of rt_render_kernel from algorithmic flops and
+  roofline     — FP32-VALU roofline of rt_stream_kernel from algorithmic flops and
                  the kernel's live HIP-event duration on its launch stream;
   cpu_baseline — the FP64 C++ restatement of the reference (oracle/, "port") timed on this
-                 host's cores on a bounded row sample of the same workload (rank 0, N = 1 only).
+                 host's cores on a bounded number of whole frames of the same workload (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -55,8 +55,8 @@ def build_scene(wl):
 
 
 def cpu_baseline(wl, target_s=15.0):
-    """Time the oracle (FP64 restatement of the reference) on this host, all cores, on every k-th
-    row of one frame of the same workload."""
+    """Time the oracle (FP64 restatement of the reference) on this host, all cores, on whole frames
+    of the same workload until ~target_s seconds of CPU time have been spent."""
     import numpy as np
     from oracle import cpu_oracle
     w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
@@ -77,10 +77,9 @@ def cpu_baseline(wl, target_s=15.0):
         return rays, dt
 
     # whole frames of the workload (seed = frame index) until ~target_s of CPU time is spent
-    rows = np.arange(h)
     rays = frames = 0
     dt = 0.0
-    while dt < target_s and frames < 64:
+    while dt < target_s and frames < 1024:
         r_, d_ = run_frame(frames)
         rays += r_; dt += d_; frames += 1
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
