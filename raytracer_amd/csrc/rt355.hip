@@ -35,6 +35,9 @@
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4   // __launch_bounds__ occupancy target: caps VGPRs at 512/4 = 128
 #endif
+#ifndef RT_SHADOW_CHEAP
+#define RT_SHADOW_CHEAP 1 // shadow scan: plain discriminant + exact fallback in the ambiguous band
+#endif
 #ifndef RT_GEOM_SRC
 #define RT_GEOM_SRC 0     // shadow scan reads spheres from: 0 LDS, 1 LDS prefetched, 2 scalar loads
 #endif
@@ -327,18 +330,42 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
     auto test_sphere = [&](const float4 g) {
       const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
       const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
-      const float r2 = (c > 0.0f) ? g.w : -INFINITY;
+#if RT_SHADOW_CHEAP
+      // Two-tier test.  Tier 1 is the plain discriminant nb^2 - c (4 ops per ray): its FP32 error is
+      // below 2^-20 |co|^2 (3 roundings in nb, 3 in c, |L|^2 = 1 +- 4 ulp), so with thr = 2^-18 |co|^2
+      //   dh = nb^2 - (c + thr) >= 0  is a certain hit, and  dh + 2 thr < 0  a certain miss.
+      // Only a verdict inside that band (a ray within ~1 % of a silhouette) needs tier 2, the
+      // cancellation-free r^2 - |l|^2 form, and it is evaluated for the lanes that saw such a ray
+      // (~1 % of sphere iterations).  Certain hits re-evaluated by tier 2 stay hits.
+      const float thr = (c + g.w) * (1.0f / 262144.0f);
+      const float chi = (c > 0.0f) ? c + thr : INFINITY;   // origin inside the sphere: never hit
+      const float thr2 = thr + thr;
+      uint32_t amb = 0u;
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
-        const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
-        const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
-#if RT_ACC_BITS
-        m[k] = __uint_as_float(__float_as_uint(m[k]) & (__float_as_uint(dl) | __float_as_uint(nb)));
-        asm volatile("" : "+v"(m[k]));   // keep the and-chain sequential (no reassociation tree)
-#else
-        m[k] = __builtin_fmaxf(m[k], __builtin_fminf(dl, nb));
+        const float dh = fmaf(nb, nb, -chi);
+        const float dlo = dh + thr2;
+        m[k] = __uint_as_float(__float_as_uint(m[k]) & (__float_as_uint(dh) | __float_as_uint(nb)));
+        amb |= __float_as_uint(dh) & ~__float_as_uint(dlo);   // sign set: dh < 0 <= dh + 2 thr
+        asm volatile("" : "+v"(m[k]), "+v"(amb));   // keep both chains sequential (no reassociation tree)
+      }
+      if (int(amb) < 0)
 #endif
+      {
+        const float r2 = (c > 0.0f) ? g.w : -INFINITY;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
+          const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
+          const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
+#if RT_ACC_BITS
+          m[k] = __uint_as_float(__float_as_uint(m[k]) & (__float_as_uint(dl) | __float_as_uint(nb)));
+          asm volatile("" : "+v"(m[k]));   // keep the and-chain sequential (no reassociation tree)
+#else
+          m[k] = __builtin_fmaxf(m[k], __builtin_fminf(dl, nb));
+#endif
+        }
       }
     };
 #if RT_GEOM_SRC == 1
