@@ -71,6 +71,7 @@ struct RenderParams {
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
+  int16_t* vis;            // [frame][n_rows][nx] primary hit index (-1 = miss), visibility pass -> stream kernel
   uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
   float* out_f32;        // [frame][n_rows][nx][3] or null (render_chunk)
   int32_t* out_hit;      // [frame][n_rows][nx] or null
@@ -191,6 +192,17 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const
 // silhouette by < 1 % of a pixel and is far inside the grazing-tie margin); the hit distance of
 // the chosen sphere is then recomputed once in the cancellation-free form of nearest_hit.
 // ------------------------------------------------------------------------------------------
+// intersect_sphere (raytracer.py:93-104) for ONE known sphere in the cancellation-free form of
+// nearest_hit: returns t (valid iff dl >= 0 and t > 0).
+__device__ __forceinline__ float sphere_t_exact(const float4 s, float ox, float oy, float oz, float dx,
+                                                float dy, float dz, float inv_a, float& dl) {
+  const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+  const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
+  const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
+  dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));
+  return q - fsqrt(dl * inv_a);
+}
+
 // table entry: four spheres, struct-of-arrays, so one s_load_dwordx16 brings a group and packed
 // VALU ops find sphere pairs in adjacent SGPRs.  w holds -c (or -inf where the camera is inside).
 struct __attribute__((aligned(64))) CamGroup {
@@ -232,12 +244,8 @@ __device__ __forceinline__ void primary_hit(const float4* __restrict__ sg, const
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (disc[j] >= 0.0f && nb[j] > 0.0f) {
-          const float4 s = sg[min(4 * g + j, n - 1)];
-          const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-          const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
-          const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
-          const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));
-          const float t = q - fsqrt(dl * inv_a);
+          float dl;
+          const float t = sphere_t_exact(sg[min(4 * g + j, n - 1)], ox, oy, oz, dx, dy, dz, inv_a, dl);
           if (dl >= 0.0f && t > 0.0f && t < best_t) {
             best_t = t;
             best_i = 4 * g + j;
@@ -541,6 +549,50 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// VISIBILITY PASS (first half of the default path).  One thread per pixel: primary ray
+// (render_pixel :293-295) and its find_nearest_intersection over all N spheres, result = the hit
+// sphere index as int16 (2 B per pixel through L2/HBM; the hit distance is recomputed by the
+// consumer with the same expressions).  Primary rays are 4 VALU ops per sphere but sit behind a
+// long dependent set-up (RNG hash chain, two divides, scalar table loads, candidate branches): run
+// inside the shading kernel at 4 waves/SIMD that latency left the VALU idle; here ~40 VGPRs allow
+// 8 waves/SIMD to hide it.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* sg = reinterpret_cast<float4*>(smem);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
+  __syncthreads();
+  const int tiles_x = (p.nx + kTileW - 1) / kTileW, tiles_y = (p.n_rows + kTileH - 1) / kTileH;
+  const int frame = blockIdx.x / (tiles_x * tiles_y);
+  const int tile = blockIdx.x - frame * (tiles_x * tiles_y);
+  const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = tile_x * kTileW + wave * 8 + (lane & 7), row = tile_y * kTileH + (lane >> 3);
+  if (col < p.nx && row < p.n_rows) {
+    const rt_camera& cam = p.cams[frame];
+    const int x = p.x0 + col, y = row_of(p, row);
+    uint32_t pixel_key;
+    float dx, dy, dz, t;
+    int idx;
+    primary_ray<MODE>(p, cam, p.seeds[frame], x, y, p.sample_index, pixel_key, dx, dy, dz);
+    primary_hit(sg, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, cam.origin[0],
+                cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+    const long long wpix = (long long)row * p.nx + col;
+    p.vis[(long long)frame * p.accum_stride_px + wpix] = int16_t(idx);
+    if (p.out_hit && p.sample_index + 1 == p.n_samples)
+      p.out_hit[(long long)frame * p.frame_stride_px + wpix] = idx;
+  }
+  if (tid == 0 && p.counters) {   // every pixel of the tile is one primary ray
+    const int cols = min(kTileW, p.nx - tile_x * kTileW), rows = min(kTileH, p.n_rows - tile_y * kTileH);
+    unsigned long long* slot = p.counters + size_t(blockIdx.x % kCounterSlots) * kCounterWords;
+    atomicAdd(slot + 0, (unsigned long long)(rows * cols));
+    atomicAdd(slot + 2, (unsigned long long)(rows * cols));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // STREAM KERNEL (default).  One workgroup renders a 64 x 32 pixel strip of one frame.
 //
 //   fill phase : the 4 waves each trace the primary rays of one 8x8 tile (all 64 lanes active);
@@ -600,7 +652,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   const uint32_t seed32 = p.seeds[frame];
   const long long frame_px = (long long)frame * p.frame_stride_px;
   const long long accum_px = (long long)frame * p.accum_stride_px;
-  const CamGroup* camtab = p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2);
   __syncthreads();
 
   uint32_t n_trace = 0, n_shade = 0;
@@ -620,25 +671,22 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       const int tile = fill * 4 + wave;
       const int lx = (tile & 7) * 8 + (lane & 7), ly = (tile >> 3) * 8 + (lane >> 3);
       const bool active = (lx < cols) && (ly < rows);
-      bool hit = false;
       float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
       int idx = -1;
-      if (active) {
+      const long long wpix = (long long)(row0 + ly) * p.nx + (col0 + lx);
+      if (active) idx = p.vis[accum_px + wpix];
+      const bool hit = idx >= 0;
+      if (active && !hit)                                            // :237-238 miss -> black
+        finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &stage[ly * kStripW + lx]);
+      if (hit) {
+        // rebuild the primary ray and its hit point exactly as the visibility pass measured them
         const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
         uint32_t pixel_key;
         primary_ray<MODE>(p, cam, seed32, x, y, p.sample_index, pixel_key, dx, dy, dz);
-        float t;
-        ++n_trace;
-        primary_hit(sg, camtab, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
-        hit = idx >= 0;
-        const long long gpix = frame_px + (long long)(row0 + ly) * p.nx + (col0 + lx);
-        if (p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[gpix] = idx;
-        if (hit) {                                                   // :165
-          px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);
-        } else {
-          finish_pixel(p, gpix, gpix - frame_px + accum_px, 0.f, 0.f, 0.f,
-                       &stage[ly * kStripW + lx]);                 // :237-238 miss -> black
-        }
+        const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        float dl;
+        const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
+        px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
       }
       const int slot = queue_reserve(hit, push, q_count);
       if (hit) {
@@ -729,7 +777,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   __syncthreads();
   if (p.out_rgb && p.sample_index + 1 == p.n_samples)
     store_tile_rgb<kStripW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
-  if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, (unsigned long long)rows * cols);
+  if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, 0ull);   // primaries: visibility pass
 #if RT_STAMPS
   if (lane == 0 && p.counters) {   // per-wave phase sums (diagnostic build only; read by tools/stamps.py)
     unsigned long long* slot = p.counters + size_t(blockIdx.x % kCounterSlots) * kCounterWords + 8;
@@ -845,6 +893,8 @@ struct rt_ctx {
   float* d_spec = nullptr;
   unsigned long long* d_counters = nullptr;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][RT_MAX_SPHERES / 4] primary-ray tables
+  int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
+  size_t vis_elems = 0;
   float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
   size_t accum_floats = 0;
   int n_spheres = -1;
@@ -923,6 +973,18 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     }
   }
 
+  const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
+  if (stream_kernel) {  // primary-hit indices handed from the visibility pass to the stream kernel
+    const size_t need = size_t(win_px) * size_t(batch);
+    if (need > ctx->vis_elems) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_vis) RT_HIP(ctx, hipFree(ctx->d_vis));
+      ctx->d_vis = nullptr; ctx->vis_elems = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_vis, need * sizeof(int16_t)));
+      ctx->vis_elems = need;
+    }
+  }
+
   RenderParams p{};
   p.L = ctx->lights;
   p.width = width; p.height = height;
@@ -933,10 +995,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec;
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
+  p.vis = ctx->d_vis;
   p.counters = ctx->d_counters;
   p.frame_stride_px = frame_px;
   p.accum_stride_px = win_px;
-  const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   unsigned per_frame;
   if (stream_kernel) {
     p.strips_x = (w.nx + kStripW - 1) / kStripW; p.strips_y = (w.n_rows + kStripH - 1) / kStripH;
@@ -970,10 +1032,16 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     for (int s = 0; s < samples; ++s) {
       p.sample_index = s;
       if (stream_kernel) {
-        if (rng_mode == RT_RNG_KEYED)
+        const dim3 vgrid(unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH) *
+                             unsigned(nf), 1, 1);
+        const size_t vlds = geom_lds(ctx->n_spheres) + 16;
+        if (rng_mode == RT_RNG_KEYED) {
+          hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_KEYED>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
           hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
-        else
+        } else {
+          hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_CONSTANT>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
           hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_CONSTANT>, grid, dim3(kBlock), lds, ctx->stream, p);
+        }
       } else {
         if (rng_mode == RT_RNG_KEYED)
           hipLaunchKernelGGL(rt_pixel_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
@@ -1056,6 +1124,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+  if (ctx->d_vis) (void)hipFree(ctx->d_vis);
   delete ctx;
 }
 
