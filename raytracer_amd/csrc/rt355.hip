@@ -72,6 +72,9 @@ struct RenderParams {
   const float* spec;     // specular
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
   int16_t* vis;            // [frame][n_rows][nx] primary hit index (-1 = miss), visibility pass -> stream kernel
+  uint8_t* tile_hits;      // [frame][tiles8_y][tiles8_x] hit pixels per 8x8 tile (same hand-over)
+  int* chunk_counter;      // dynamic work distribution of the stream kernel (zeroed per launch)
+  int tiles8_x, tiles8_y;
   uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
   float* out_f32;        // [frame][n_rows][nx][3] or null (render_chunk)
   int32_t* out_hit;      // [frame][n_rows][nx] or null
@@ -98,7 +101,7 @@ constexpr int kTileW = 32, kTileH = 8;
 // stream kernel: 64 x 32 pixel strip per workgroup, processed as 32 tiles of 8 x 8
 constexpr int kStripW = 64, kStripH = 32, kStripTiles = 32, kStripPix = kStripW * kStripH;
 constexpr int kQueueCap = 512;     // >= 2 * kBlock - 1
-constexpr int kQueueFields = 13;   // P(3) D(3) T(3) acc(3) meta(1)
+constexpr int kQueueFields = 14;   // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1)
 
 // ------------------------------------------------------------------------------------------
 // keyed RNG — identical to oracle/ref_harness.py / oracle/rt_oracle.cpp
@@ -506,7 +509,13 @@ __device__ __forceinline__ void finish_pixel(const RenderParams& p, long long gp
     float* o = p.out_f32 + gpix * 3;
     o[0] = fminf(1.0f, fmaxf(0.0f, r)); o[1] = fminf(1.0f, fmaxf(0.0f, g)); o[2] = fminf(1.0f, fmaxf(0.0f, b));
   }
-  *stage_slot = pack_rgbx(r, g, b);
+  const uint32_t rgbx = pack_rgbx(r, g, b);
+  if (stage_slot) {
+    *stage_slot = rgbx;
+  } else if (p.out_rgb) {   // stream kernel: only hit pixels end here, scattered over the frame
+    uint8_t* o = p.out_rgb + gpix * 3;
+    o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
+  }
 }
 
 __device__ __forceinline__ void flush_counters(const RenderParams& p, unsigned int* s_cnt, unsigned slot_id,
@@ -561,6 +570,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);
+  const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
+  uint32_t* stage = reinterpret_cast<uint32_t*>(smem + geom_bytes);            // [8][32] RGBX
   const int tid = threadIdx.x;
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   __syncthreads();
@@ -569,23 +580,39 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
   const int tile = blockIdx.x - frame * (tiles_x * tiles_y);
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int col = tile_x * kTileW + wave * 8 + (lane & 7), row = tile_y * kTileH + (lane >> 3);
-  if (col < p.nx && row < p.n_rows) {
+  const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
+  const int col0 = tile_x * kTileW, row0 = tile_y * kTileH;
+  const int cols = min(kTileW, p.nx - col0), rows = min(kTileH, p.n_rows - row0);
+  const long long frame_px = (long long)frame * p.frame_stride_px;
+  const long long accum_px = (long long)frame * p.accum_stride_px;
+  int idx = -1;
+  if (lx < cols && ly < rows) {
     const rt_camera& cam = p.cams[frame];
-    const int x = p.x0 + col, y = row_of(p, row);
+    const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
     uint32_t pixel_key;
     float dx, dy, dz, t;
-    int idx;
     primary_ray<MODE>(p, cam, p.seeds[frame], x, y, p.sample_index, pixel_key, dx, dy, dz);
     primary_hit(sg, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, cam.origin[0],
                 cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
-    const long long wpix = (long long)row * p.nx + col;
-    p.vis[(long long)frame * p.accum_stride_px + wpix] = int16_t(idx);
-    if (p.out_hit && p.sample_index + 1 == p.n_samples)
-      p.out_hit[(long long)frame * p.frame_stride_px + wpix] = idx;
+    const long long wpix = (long long)(row0 + ly) * p.nx + (col0 + lx);
+    p.vis[accum_px + wpix] = int16_t(idx);
+    if (p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[frame_px + wpix] = idx;
+    if (idx < 0)   // :237-238 miss -> black (resolves the running mean over samples too)
+      finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &stage[ly * kTileW + lx]);
+    else           // placeholder; the stream kernel writes the pixel when its path ends
+      stage[ly * kTileW + lx] = 0u;
   }
+  // hit pixels per 8x8 tile (one wave = one tile): lets the stream kernel visit only tiles with work
+  const unsigned long long hits = __ballot(idx >= 0);
+  if (lane == 0) {
+    const int tx8 = tile_x * 4 + wave, ty8 = tile_y;
+    if (tx8 < p.tiles8_x && ty8 < p.tiles8_y)
+      p.tile_hits[(size_t(frame) * p.tiles8_y + ty8) * p.tiles8_x + tx8] = uint8_t(__popcll(hits));
+  }
+  __syncthreads();
+  if (p.out_rgb && p.sample_index + 1 == p.n_samples)
+    store_tile_rgb<kTileW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
   if (tid == 0 && p.counters) {   // every pixel of the tile is one primary ray
-    const int cols = min(kTileW, p.nx - tile_x * kTileW), rows = min(kTileH, p.n_rows - tile_y * kTileH);
     unsigned long long* slot = p.counters + size_t(blockIdx.x % kCounterSlots) * kCounterWords;
     atomicAdd(slot + 0, (unsigned long long)(rows * cols));
     atomicAdd(slot + 2, (unsigned long long)(rows * cols));
@@ -593,19 +620,23 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
 }
 
 // ------------------------------------------------------------------------------------------
-// STREAM KERNEL (default).  One workgroup renders a 64 x 32 pixel strip of one frame.
+// STREAM KERNEL (second half of the default path): persistent workgroups with an LDS work queue.
 //
-//   fill phase : the 4 waves each trace the primary rays of one 8x8 tile (all 64 lanes active);
-//                misses are finished at once, hits are compacted (wave ballot + one LDS atomic per
-//                wave) into the workgroup's queue of hit records in LDS.
-//   shade phase: once >= 256 records are queued (or no tile is left) each thread pops one record:
-//                compute_lighting with its 13 x N shadow tests, throughput update, reflection ray,
-//                nearest-hit scan of that ray; a new hit goes back into the queue, anything else
-//                finishes the pixel.  Popping from the tail keeps deep levels ahead of new work,
-//                so the queue never holds more than 511 records.
-// Lanes therefore only idle in the last partial batch of a strip, instead of wherever a wave's
-// pixels miss or die at different depths (the pixel kernel below, kept for A/B evidence).
-// Finished pixels are staged as RGBX words in LDS and leave as whole-dword packed-RGB rows.
+// The launch holds ~4 workgroups per CU; each pulls chunks (64 x 32 pixels of one frame of the
+// batch) from a global counter until none is left.  Per chunk the visibility pass has left the
+// hit sphere of every pixel and the hit count of every 8x8 tile, so only tiles with hits are
+// visited:
+//   fill phase : each of the 4 waves takes one non-empty tile, rebuilds the primary ray and hit
+//                point of its hit pixels and pushes them (wave ballot + one LDS atomic per wave)
+//                onto the workgroup's queue of records {P, D, T, acc, pixel, level|frame|sphere}.
+//   shade phase: once >= 256 records are queued (or no chunk is left) each thread pops one
+//                record: compute_lighting with its 13 x N shadow tests, throughput update,
+//                reflection ray, nearest-hit scan of that ray; a new hit goes back onto the queue,
+//                anything else finishes the pixel (3 byte stores into the frame the visibility pass
+//                has already cleared).
+// The queue lives across chunks and frames, so waves only run partially filled in the final drain
+// of a workgroup — not wherever a wave's pixels miss or die at different depths (the pixel kernel
+// below, kept for A/B evidence), and not at the end of every strip either.
 // ------------------------------------------------------------------------------------------
 struct Queue {
   float* f;        // kQueueFields arrays of kQueueCap words
@@ -632,57 +663,79 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   float4* sg = reinterpret_cast<float4*>(smem);
   const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
   Queue q{reinterpret_cast<float*>(smem + geom_bytes)};
-  uint32_t* stage = reinterpret_cast<uint32_t*>(smem + geom_bytes + kQueueFields * kQueueCap * 4);
-  unsigned int* s_push = reinterpret_cast<unsigned int*>(stage + kStripPix);  // [3] rotating counters
-  unsigned int* s_cnt = s_push + 4;                                           // [2] ray statistics
+  unsigned int* s_push = reinterpret_cast<unsigned int*>(smem + geom_bytes + kQueueFields * kQueueCap * 4);  // [3]
+  unsigned int* s_cnt = s_push + 4;                        // [2] ray statistics
+  int* s_chunk = reinterpret_cast<int*>(s_push + 6);       // [2] alternating hand-over of fetched chunk ids
+  uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_push + 8);  // [kMaxBatch]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   if (tid < 3) s_push[tid] = 0u;
   if (tid < 2) s_cnt[tid] = 0u;
-
-  // workgroup -> (frame, strip)
-  const int strips = p.strips_x * p.strips_y;
-  const int frame = blockIdx.x / strips;
-  const int strip = blockIdx.x - frame * strips;
-  const int strip_y = strip / p.strips_x, strip_x = strip - strip_y * p.strips_x;
-  const int col0 = strip_x * kStripW, row0 = strip_y * kStripH;     // window coordinates
-  const int cols = min(kStripW, p.nx - col0), rows = min(kStripH, p.n_rows - row0);
-  const rt_camera& cam = p.cams[frame];
-  const uint32_t seed32 = p.seeds[frame];
-  const long long frame_px = (long long)frame * p.frame_stride_px;
-  const long long accum_px = (long long)frame * p.accum_stride_px;
+  if (tid < kMaxBatch) s_seeds[tid] = p.seeds[tid];
   __syncthreads();
 
+  const int strips = p.strips_x * p.strips_y;
+  const int total_chunks = strips * p.n_frames;
   uint32_t n_trace = 0, n_shade = 0;
   unsigned long long st_fill = 0, st_fbar = 0, st_pop = 0, st_light = 0, st_near = 0, st_sbar = 0;
   const unsigned long long st_begin = RT_NOW();
-  int q_count = 0;   // uniform across the workgroup
-  int fill = 0;      // next group of 4 tiles
-  int phase = 0;     // selects the rotating push counter
-  constexpr int kFillSteps = kStripTiles / 4;
+  int q_count = 0;          // uniform across the workgroup
+  int phase = 0;            // selects the rotating push counter
+  int n_fetch = 0;
+  bool done = false;        // the chunk counter is exhausted
+  uint32_t fill_mask = 0;   // non-empty tiles of the current chunk not yet consumed
+  int frame = 0, col0 = 0, row0 = 0, cols = 0, rows = 0;
 
   for (;;) {
     // ------------------------------ fill -------------------------------------------------
-    while (q_count < kBlock && fill < kFillSteps) {
+    while (q_count < kBlock && !(done && fill_mask == 0u)) {
       const unsigned long long s0 = RT_NOW();
+      if (fill_mask == 0u) {   // fetch the next chunk (one returning atomic per 2048 pixels)
+        if (tid == 0) s_chunk[n_fetch & 1] = atomicAdd(p.chunk_counter, 1);
+        __syncthreads();
+        const int chunk = s_chunk[n_fetch & 1];
+        ++n_fetch;
+        if (chunk >= total_chunks) {
+          done = true;
+        } else {
+          frame = chunk / strips;
+          const int strip = chunk - frame * strips;
+          const int strip_y = strip / p.strips_x, strip_x = strip - strip_y * p.strips_x;
+          col0 = strip_x * kStripW; row0 = strip_y * kStripH;       // window coordinates
+          cols = min(kStripW, p.nx - col0); rows = min(kStripH, p.n_rows - row0);
+          const int tx8 = (col0 >> 3) + (lane & 7), ty8 = (row0 >> 3) + ((lane >> 3) & 3);
+          int cnt = 0;
+          if (lane < kStripTiles && tx8 < p.tiles8_x && ty8 < p.tiles8_y)
+            cnt = p.tile_hits[(size_t(frame) * p.tiles8_y + ty8) * p.tiles8_x + tx8];
+          fill_mask = uint32_t(__ballot(cnt > 0));                   // bit t = tile (t & 7, t >> 3)
+        }
+        st_fbar += RT_NOW() - s0;
+        continue;
+      }
       unsigned int* push = s_push + (phase % 3);
       if (tid == 0) s_push[(phase + 1) % 3] = 0u;
-      const int tile = fill * 4 + wave;
-      const int lx = (tile & 7) * 8 + (lane & 7), ly = (tile >> 3) * 8 + (lane >> 3);
-      const bool active = (lx < cols) && (ly < rows);
+      // the next four non-empty tiles, one per wave
+      int tile = -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (fill_mask != 0u) {
+          if (j == wave) tile = __ffs(int(fill_mask)) - 1;
+          fill_mask &= fill_mask - 1u;
+        }
+      }
       float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
       int idx = -1;
-      const long long wpix = (long long)(row0 + ly) * p.nx + (col0 + lx);
-      if (active) idx = p.vis[accum_px + wpix];
+      const int lx = (tile & 7) * 8 + (lane & 7), ly = (tile >> 3) * 8 + (lane >> 3);
+      const uint32_t wpix = uint32_t(row0 + ly) * uint32_t(p.nx) + uint32_t(col0 + lx);
+      if (tile >= 0 && lx < cols && ly < rows) idx = p.vis[(long long)frame * p.accum_stride_px + wpix];
       const bool hit = idx >= 0;
-      if (active && !hit)                                            // :237-238 miss -> black
-        finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &stage[ly * kStripW + lx]);
       if (hit) {
         // rebuild the primary ray and its hit point exactly as the visibility pass measured them
+        const rt_camera& cam = p.cams[frame];
         const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
         uint32_t pixel_key;
-        primary_ray<MODE>(p, cam, seed32, x, y, p.sample_index, pixel_key, dx, dy, dz);
+        primary_ray<MODE>(p, cam, s_seeds[frame], x, y, p.sample_index, pixel_key, dx, dy, dz);
         const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
         float dl;
         const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
@@ -694,14 +747,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
         q.at(6, slot) = 1.f; q.at(7, slot) = 1.f; q.at(8, slot) = 1.f;
         q.at(9, slot) = 0.f; q.at(10, slot) = 0.f; q.at(11, slot) = 0.f;
-        // meta: local pixel (11 bits) | level (7 bits) | sphere index (13 bits)
-        q.at(12, slot) = __uint_as_float(uint32_t(ly * kStripW + lx) | (0u << 11) | (uint32_t(idx) << 18));
+        q.at(12, slot) = __uint_as_float(wpix);
+        // meta: level (8 bits) | frame (8 bits) | sphere index (16 bits)
+        q.at(13, slot) = __uint_as_float(0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16));
       }
       const unsigned long long s1 = RT_NOW();
       __syncthreads();
       st_fill += s1 - s0; st_fbar += RT_NOW() - s1;
       q_count += int(*push);
-      ++fill;
       ++phase;
     }
     if (q_count == 0) break;
@@ -715,25 +768,26 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       const int base = q_count - n_pop;
       const bool have = tid < n_pop;
       float px, py, pz, dx, dy, dz, tr, tg, tb, ar, ag, ab;
-      uint32_t meta = 0;
+      uint32_t wpix = 0, meta = 0;
       if (have) {
         const int e = base + tid;
         px = q.at(0, e); py = q.at(1, e); pz = q.at(2, e);
         dx = q.at(3, e); dy = q.at(4, e); dz = q.at(5, e);
         tr = q.at(6, e); tg = q.at(7, e); tb = q.at(8, e);
         ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e);
-        meta = __float_as_uint(q.at(12, e));
+        wpix = __float_as_uint(q.at(12, e));
+        meta = __float_as_uint(q.at(13, e));
       }
       __syncthreads();   // every record of this batch is in registers before slots are reused
       const unsigned long long s1 = RT_NOW();
       unsigned long long s2 = s1;
       bool again = false;
-      int idx2 = -1;
       if (have) {
-        const int lpix = int(meta & 2047u), level = int((meta >> 11) & 127u), idx = int(meta >> 18);
-        const int lx = lpix & (kStripW - 1), ly = lpix >> 6;
-        const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
-        const uint32_t pixel_key = mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(p.sample_index));
+        const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
+        const int prow = int(wpix / uint32_t(p.nx)), pcol = int(wpix - uint32_t(prow) * uint32_t(p.nx));
+        const int x = p.x0 + pcol, y = row_of(p, prow);
+        const uint32_t pixel_key =
+            mix(mix(mix(s_seeds[rframe], uint32_t(x)), uint32_t(y)), uint32_t(p.sample_index));
         ++n_shade;
         float ox, oy, oz;
         bool cont = shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, mix(pixel_key, uint32_t(level + 1)),
@@ -742,18 +796,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         s2 = RT_NOW();
         if (cont) {
           float t;
+          int idx2;
           ++n_trace;
           nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);
           if (idx2 >= 0) {
             again = true;
             px = fmaf(dx, t, ox); py = fmaf(dy, t, oy); pz = fmaf(dz, t, oz);
-            meta = uint32_t(lpix) | (uint32_t(level + 1) << 11) | (uint32_t(idx2) << 18);
+            meta = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
           }
         }
-        if (!again) {
-          const long long gpix = frame_px + (long long)(row0 + ly) * p.nx + (col0 + lx);
-          finish_pixel(p, gpix, gpix - frame_px + accum_px, ar, ag, ab, &stage[lpix]);
-        }
+        if (!again)
+          finish_pixel(p, (long long)rframe * p.frame_stride_px + wpix,
+                       (long long)rframe * p.accum_stride_px + wpix, ar, ag, ab, nullptr);
       }
       const int slot = queue_reserve(again, push, base);
       if (again) {
@@ -761,7 +815,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
         q.at(6, slot) = tr; q.at(7, slot) = tg; q.at(8, slot) = tb;
         q.at(9, slot) = ar; q.at(10, slot) = ag; q.at(11, slot) = ab;
-        q.at(12, slot) = __uint_as_float(meta);
+        q.at(12, slot) = __uint_as_float(wpix);
+        q.at(13, slot) = __uint_as_float(meta);
       }
       const unsigned long long s3 = RT_NOW();
       __syncthreads();
@@ -771,12 +826,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
     }
   }
 
-  // ---- ray statistics + packed-RGB store -------------------------------------------------------
+  // ---- ray statistics ---------------------------------------------------------------------------
   if (n_trace) atomicAdd(&s_cnt[0], n_trace);
   if (n_shade) atomicAdd(&s_cnt[1], n_shade);
   __syncthreads();
-  if (p.out_rgb && p.sample_index + 1 == p.n_samples)
-    store_tile_rgb<kStripW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
   if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, 0ull);   // primaries: visibility pass
 #if RT_STAMPS
   if (lane == 0 && p.counters) {   // per-wave phase sums (diagnostic build only; read by tools/stamps.py)
@@ -894,7 +947,10 @@ struct rt_ctx {
   unsigned long long* d_counters = nullptr;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][RT_MAX_SPHERES / 4] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
+  uint8_t* d_tile_hits = nullptr;  // [batch][8x8 tiles of the window]
+  int* d_chunk = nullptr;        // stream kernel's chunk counter (64 ints, only [0] used)
   size_t vis_elems = 0;
+  int n_cus = 256;
   float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
   size_t accum_floats = 0;
   int n_spheres = -1;
@@ -924,7 +980,7 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
 size_t stream_lds(int n_spheres) {
-  return geom_lds(n_spheres) + size_t(kQueueFields) * kQueueCap * 4 + size_t(kStripPix) * 4 + 32;
+  return geom_lds(n_spheres) + size_t(kQueueFields) * kQueueCap * 4 + 32 + 4 * kMaxBatch + 16;
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -979,8 +1035,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     if (need > ctx->vis_elems) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_vis) RT_HIP(ctx, hipFree(ctx->d_vis));
-      ctx->d_vis = nullptr; ctx->vis_elems = 0;
+      if (ctx->d_tile_hits) RT_HIP(ctx, hipFree(ctx->d_tile_hits));
+      ctx->d_vis = nullptr; ctx->d_tile_hits = nullptr; ctx->vis_elems = 0;
       RT_HIP(ctx, hipMalloc(&ctx->d_vis, need * sizeof(int16_t)));
+      // an 8x8 tile grid never has more tiles than pixels / 8 + rows + cols
+      RT_HIP(ctx, hipMalloc(&ctx->d_tile_hits, need / 8 + size_t(batch) * size_t(w.nx + w.n_rows + 8)));
       ctx->vis_elems = need;
     }
   }
@@ -996,6 +1055,9 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
   p.vis = ctx->d_vis;
+  p.tile_hits = ctx->d_tile_hits;
+  p.chunk_counter = ctx->d_chunk;
+  p.tiles8_x = (w.nx + 7) / 8; p.tiles8_y = (w.n_rows + 7) / 8;
   p.counters = ctx->d_counters;
   p.frame_stride_px = frame_px;
   p.accum_stride_px = win_px;
@@ -1034,13 +1096,16 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       if (stream_kernel) {
         const dim3 vgrid(unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH) *
                              unsigned(nf), 1, 1);
-        const size_t vlds = geom_lds(ctx->n_spheres) + 16;
+        const size_t vlds = pixel_lds(ctx->n_spheres);
+        // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
+        const dim3 sgrid(std::min(grid.x, unsigned(ctx->n_cus * RT_WAVES_PER_SIMD)), 1, 1);
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, 256, ctx->stream));
         if (rng_mode == RT_RNG_KEYED) {
           hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_KEYED>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
-          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
+          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_KEYED>, sgrid, dim3(kBlock), lds, ctx->stream, p);
         } else {
           hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_CONSTANT>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
-          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_CONSTANT>, grid, dim3(kBlock), lds, ctx->stream, p);
+          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_CONSTANT>, sgrid, dim3(kBlock), lds, ctx->stream, p);
         }
       } else {
         if (rng_mode == RT_RNG_KEYED)
@@ -1100,6 +1165,8 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * (RT_MAX_SPHERES / 4) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_chunk, 256)) != hipSuccess) return bail(e, "hipMalloc");
+  ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
@@ -1125,6 +1192,8 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);
+  if (ctx->d_tile_hits) (void)hipFree(ctx->d_tile_hits);
+  if (ctx->d_chunk) (void)hipFree(ctx->d_chunk);
   delete ctx;
 }
 
