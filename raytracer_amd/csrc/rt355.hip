@@ -67,6 +67,9 @@ struct RenderParams {
   int max_depth;
   int n_spheres;
   int n_frames, strips_x, strips_y;
+  float inv_w, inv_h;    // RN(1/width), RN(1/height): div_exact() turns them into true quotients
+  float inv_aspect;      // RN(height/width)
+  float inv_samples;     // RN(1/n_samples)
   const float4* geom;    // cx cy cz r^2
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
@@ -137,6 +140,15 @@ __device__ __forceinline__ cgeom_t as_const(const float4* p) { return p; }
 __device__ __forceinline__ float pow50(float x) {  // `** 50` (raytracer.py:193,208), x >= 0
   float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16;
   return x32 * x16 * x2;
+}
+
+// a / b, correctly rounded, given rb = RN(1/b): q = RN(a*rb) is within an ulp, the fma residual
+// a - q*b is exact, and RN(q + r*rb) is then the correctly rounded quotient (Markstein's theorem; b
+// is an image size <= 2^20, so its significand is never all ones).  Three full-rate ops instead of
+// the ~11 of the IEEE division expansion; tools/check_div.c verifies bit-equality with `/`.
+__device__ __forceinline__ float div_exact(float a, float b, float rb) {
+  const float q = a * rb;
+  return fmaf(fmaf(-q, b, a), rb, q);
 }
 
 // image row of local row lr (rt_render_rows tiling; full frames use tile_rows = height)
@@ -219,13 +231,14 @@ typedef const CamGroup* camtab_t;
 __device__ __forceinline__ camtab_t as_const(const CamGroup* p) { return p; }
 #endif
 
-__device__ __forceinline__ void primary_hit(const float4* __restrict__ sg, const CamGroup* __restrict__ camtab,
+__device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
                                             int n, float ox, float oy, float oz, float dx, float dy,
                                             float dz, float& best_t, int& best_i) {
   best_t = INFINITY;
   best_i = -1;
   const int ngroups = (n + 3) >> 2;   // the table is padded with never-hit entries
   camtab_t tab = as_const(camtab);
+  cgeom_t geom = as_const(gg);   // candidates are rare: their sphere comes by scalar load
   const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
   if (ngroups == 0) return;
   CamGroup cur = tab[0];
@@ -248,7 +261,7 @@ __device__ __forceinline__ void primary_hit(const float4* __restrict__ sg, const
       for (int j = 0; j < 4; ++j) {
         if (disc[j] >= 0.0f && nb[j] > 0.0f) {
           float dl;
-          const float t = sphere_t_exact(sg[min(4 * g + j, n - 1)], ox, oy, oz, dx, dy, dz, inv_a, dl);
+          const float t = sphere_t_exact(geom[min(4 * g + j, n - 1)], ox, oy, oz, dx, dy, dz, inv_a, dl);
           if (dl >= 0.0f && t > 0.0f && t < best_t) {
             best_t = t;
             best_i = 4 * g + j;
@@ -472,15 +485,15 @@ template <int MODE>
 __device__ __forceinline__ void primary_ray(const RenderParams& p, const rt_camera& cam, uint32_t seed32,
                                             int x, int y, int sidx, uint32_t& pixel_key, float& dx,
                                             float& dy, float& dz) {
-  // (x + r) / W and (y + r) / H stay true divisions: with a reciprocal multiply the centre column of
-  // an odd-width frame is no longer exactly u = 0, and mirror-to-mirror paths amplify that 3e-8 by
-  // ~10x per bounce (tests: facing mirrors).  1/aspect is applied as a multiply.
+  // (x + r) / W and (y + r) / H stay true (correctly rounded) quotients: with a plain reciprocal
+  // multiply the centre column of an odd-width frame is no longer exactly u = 0, and mirror-to-mirror
+  // paths amplify that 3e-8 by ~10x per bounce (tests: facing mirrors).  1/aspect is a multiply.
   const float fw = float(p.width), fh = float(p.height);
-  const float inv_aspect = fh / fw;                                                           // :290
+  const float inv_aspect = p.inv_aspect;                                                      // :290
   pixel_key = mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(sidx));
   const uint32_t jk = mix(pixel_key, 0u);
-  const float u = ((float(x) + draw<MODE>(jk, 0u)) / fw) * 2.0f - 1.0f;                       // :293
-  const float v = -(((float(y) + draw<MODE>(jk, 1u)) / fh) * 2.0f - 1.0f) * inv_aspect;       // :294
+  const float u = div_exact(float(x) + draw<MODE>(jk, 0u), fw, p.inv_w) * 2.0f - 1.0f;                  // :293
+  const float v = -(div_exact(float(y) + draw<MODE>(jk, 1u), fh, p.inv_h) * 2.0f - 1.0f) * inv_aspect;  // :294
   dx = fmaf(cam.up[0], v, cam.right[0] * u) + cam.forward[0];
   dy = fmaf(cam.up[1], v, cam.right[1] * u) + cam.forward[1];
   dz = fmaf(cam.up[2], v, cam.right[2] * u) + cam.forward[2];
@@ -502,7 +515,7 @@ __device__ __forceinline__ void finish_pixel(const RenderParams& p, long long gp
     float* a = p.accum + apix * 3;
     if (p.sample_index > 0) { r += a[0]; g += a[1]; b += a[2]; }       // color = color + trace (:296)
     if (p.sample_index + 1 < p.n_samples) { a[0] = r; a[1] = g; a[2] = b; return; }
-    const float inv_s = 1.0f / float(p.n_samples);                      // :297
+    const float inv_s = p.inv_samples;                                  // :297
     r *= inv_s; g *= inv_s; b *= inv_s;
   }
   if (p.out_f32) {                                                      // render_chunk (:305)
@@ -558,64 +571,76 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
 }
 
 // ------------------------------------------------------------------------------------------
-// VISIBILITY PASS (first half of the default path).  One thread per pixel: primary ray
-// (render_pixel :293-295) and its find_nearest_intersection over all N spheres, result = the hit
-// sphere index as int16 (2 B per pixel through L2/HBM; the hit distance is recomputed by the
-// consumer with the same expressions).  Primary rays are 4 VALU ops per sphere but sit behind a
-// long dependent set-up (RNG hash chain, two divides, scalar table loads, candidate branches): run
-// inside the shading kernel at 4 waves/SIMD that latency left the VALU idle; here ~40 VGPRs allow
-// 8 waves/SIMD to hide it.
+// VISIBILITY PASS (first half of the default path).  One thread per pixel, one wave per 8x8 tile
+// (workgroup = 4 tiles side by side; grid = tile rows x tile columns/4 x frames, so no index
+// arithmetic beyond blockIdx): primary ray (render_pixel :293-295) and its
+// find_nearest_intersection over all N spheres.  Output per pixel: the hit sphere index as int16
+// (2 B through L2/HBM; the consumer recomputes the hit distance with the same expressions), and
+// the frame itself — black where the ray misses (:237-238), a placeholder where the stream kernel
+// will write.  Per tile: the number of hit pixels, so the stream kernel visits only tiles with work.
+// The kernel is issue-bound (profiles/r1e_*: ~500 instructions per wave, scalar ones included, and
+// gfx950 issues scalar and vector instructions of a SIMD's waves from one ~1.2 instr/ns budget:
+// profiles/r1_ubench_issue_mix.txt), so it has no LDS staging, no barrier and no per-lane divisions:
+// the packed RGB rows of a tile (24 B each) are assembled across lanes with ds_bpermute.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  float4* sg = reinterpret_cast<float4*>(smem);
-  const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
-  uint32_t* stage = reinterpret_cast<uint32_t*>(smem + geom_bytes);            // [8][32] RGBX
-  const int tid = threadIdx.x;
-  for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
-  __syncthreads();
-  const int tiles_x = (p.nx + kTileW - 1) / kTileW, tiles_y = (p.n_rows + kTileH - 1) / kTileH;
-  const int frame = blockIdx.x / (tiles_x * tiles_y);
-  const int tile = blockIdx.x - frame * (tiles_x * tiles_y);
-  const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
-  const int col0 = tile_x * kTileW, row0 = tile_y * kTileH;
-  const int cols = min(kTileW, p.nx - col0), rows = min(kTileH, p.n_rows - row0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.z;
+  const int col0 = (int(blockIdx.y) * 4 + wave) * 8, row0 = int(blockIdx.x) * 8;   // window coordinates
+  const int lx = lane & 7, ly = lane >> 3;
+  const int cols = min(8, p.nx - col0), rows = min(8, p.n_rows - row0);
+  if (cols <= 0) return;                                  // wave-uniform: tile beyond the right edge
   const long long frame_px = (long long)frame * p.frame_stride_px;
   const long long accum_px = (long long)frame * p.accum_stride_px;
+  const bool last_sample = p.sample_index + 1 == p.n_samples;
+  const bool live = lx < cols && ly < rows;
+  const long long wpix = (long long)(row0 + ly) * p.nx + (col0 + lx);
   int idx = -1;
-  if (lx < cols && ly < rows) {
+  uint32_t rgbx = 0u;                                     // hit pixels: placeholder
+  if (live) {
     const rt_camera& cam = p.cams[frame];
-    const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
+    int y;                                                // image row of window row row0 + ly
+    if (p.tile_stride == 1) {                             // contiguous rows (single GPU, render_chunk)
+      y = p.y0 + p.tile_first * p.tile_rows + row0 + ly;
+    } else if ((p.tile_rows & 7) == 0) {                  // the 8 rows share a row tile: scalar arithmetic
+      const int j = row0 / p.tile_rows;
+      y = p.y0 + (p.tile_first + j * p.tile_stride) * p.tile_rows + (row0 - j * p.tile_rows) + ly;
+    } else {
+      y = row_of(p, row0 + ly);
+    }
     uint32_t pixel_key;
     float dx, dy, dz, t;
-    primary_ray<MODE>(p, cam, p.seeds[frame], x, y, p.sample_index, pixel_key, dx, dy, dz);
-    primary_hit(sg, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, cam.origin[0],
+    primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + lx, y, p.sample_index, pixel_key, dx, dy, dz);
+    primary_hit(p.geom, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, cam.origin[0],
                 cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
-    const long long wpix = (long long)(row0 + ly) * p.nx + (col0 + lx);
     p.vis[accum_px + wpix] = int16_t(idx);
-    if (p.out_hit && p.sample_index + 1 == p.n_samples) p.out_hit[frame_px + wpix] = idx;
+    if (p.out_hit && last_sample) p.out_hit[frame_px + wpix] = idx;
     if (idx < 0)   // :237-238 miss -> black (resolves the running mean over samples too)
-      finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &stage[ly * kTileW + lx]);
-    else           // placeholder; the stream kernel writes the pixel when its path ends
-      stage[ly * kTileW + lx] = 0u;
+      finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &rgbx);
   }
-  // hit pixels per 8x8 tile (one wave = one tile): lets the stream kernel visit only tiles with work
   const unsigned long long hits = __ballot(idx >= 0);
-  if (lane == 0) {
-    const int tx8 = tile_x * 4 + wave, ty8 = tile_y;
-    if (tx8 < p.tiles8_x && ty8 < p.tiles8_y)
-      p.tile_hits[(size_t(frame) * p.tiles8_y + ty8) * p.tiles8_x + tx8] = uint8_t(__popcll(hits));
-  }
-  __syncthreads();
-  if (p.out_rgb && p.sample_index + 1 == p.n_samples)
-    store_tile_rgb<kTileW>(p.out_rgb + frame_px * 3, stage, p.nx, row0, col0, rows, cols, tid);
-  if (tid == 0 && p.counters) {   // every pixel of the tile is one primary ray
-    unsigned long long* slot = p.counters + size_t(blockIdx.x % kCounterSlots) * kCounterWords;
-    atomicAdd(slot + 0, (unsigned long long)(rows * cols));
-    atomicAdd(slot + 2, (unsigned long long)(rows * cols));
+  if (lane == 0)   // col0 < nx and row0 < n_rows here, so the tile exists
+    p.tile_hits[(size_t(frame) * p.tiles8_y + (row0 >> 3)) * p.tiles8_x + (col0 >> 3)] = uint8_t(__popcll(hits));
+  if (p.out_rgb && last_sample) {
+    uint8_t* out = p.out_rgb + frame_px * 3;
+    const bool aligned = cols == 8 && (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+    if (aligned) {
+      // lane l < 48 stores dword w = l % 6 of tile row r = l / 6: bytes 4w..4w+3 of the row's 24 come
+      // from pixels a = 4w / 3 and a + 1 (RGBX words of lanes 8r + a, 8r + a + 1)
+      const int r = (lane * 43) >> 8, w = lane - 6 * r;            // l / 6 for l < 64
+      const int hi3 = w >= 3 ? 1 : 0, a = w + hi3, m = w - 3 * hi3;
+      const int src = (8 * r + a) & 63;
+      const uint32_t lo = __builtin_amdgcn_ds_bpermute(src * 4, int(rgbx));
+      const uint32_t hi = __builtin_amdgcn_ds_bpermute(((src + 1) & 63) * 4, int(rgbx));
+      const unsigned long long six = (unsigned long long)lo | ((unsigned long long)hi << 24);
+      if (lane < 48 && r < rows)
+        *reinterpret_cast<uint32_t*>(out + ((size_t)(row0 + r) * p.nx + col0) * 3 + size_t(w) * 4) =
+            uint32_t(six >> (8 * m));
+    } else if (live) {
+      uint8_t* o = out + wpix * 3;
+      o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
+    }
   }
 }
 
@@ -886,7 +911,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_pixel_kernel(con
       int idx;
       ++n_trace;
       if (level == 0)
-        primary_hit(sg, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, ox, oy, oz, dx, dy,
+        primary_hit(p.geom, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, ox, oy, oz, dx, dy,
                     dz, t, idx);
       else
         nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx);
@@ -955,6 +980,7 @@ struct rt_ctx {
   size_t accum_floats = 0;
   int n_spheres = -1;
   int kernel = RT_KERNEL_STREAM;
+  unsigned long long host_primaries = 0;  // primary rays of the visibility pass (one per pixel and sample), counted here
   DevLights lights{};
   std::string err;
 };
@@ -983,6 +1009,16 @@ size_t stream_lds(int n_spheres) {
   return geom_lds(n_spheres) + size_t(kQueueFields) * kQueueCap * 4 + 32 + 4 * kMaxBatch + 16;
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
+
+// RN(1/n) for div_exact(): the float nearest to 1/n, chosen by the exact residual |1 - n*r| (n < 2^21
+// and a 24-bit r multiply exactly in double), so double rounding cannot bite.
+float rcp_rn(int n) {
+  float best = float(1.0 / double(n));
+  const float cand[2] = {std::nextafterf(best, 0.0f), std::nextafterf(best, 2.0f)};
+  for (float c : cand)
+    if (std::fabs(1.0 - double(n) * double(c)) < std::fabs(1.0 - double(n) * double(best))) best = c;
+  return best;
+}
 
 struct Window {
   int x0, nx, n_rows, tile_rows, tile_first, tile_stride, y0;
@@ -1050,6 +1086,9 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.x0 = w.x0; p.nx = w.nx; p.n_rows = w.n_rows;
   p.tile_rows = w.tile_rows; p.tile_first = w.tile_first; p.tile_stride = w.tile_stride; p.y0 = w.y0;
   p.n_samples = samples; p.max_depth = max_depth;
+  p.inv_w = rcp_rn(width); p.inv_h = rcp_rn(height);
+  p.inv_aspect = float(height) / float(width);
+  p.inv_samples = 1.0f / float(samples);
   p.n_spheres = ctx->n_spheres;
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec;
   p.accum = ctx->d_accum;
@@ -1094,9 +1133,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     for (int s = 0; s < samples; ++s) {
       p.sample_index = s;
       if (stream_kernel) {
-        const dim3 vgrid(unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH) *
-                             unsigned(nf), 1, 1);
-        const size_t vlds = pixel_lds(ctx->n_spheres);
+        // one wave per 8x8 tile, 4 tiles (32 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
+        const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 31) / 32), unsigned(nf));
+        const size_t vlds = 0;
+        ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         const dim3 sgrid(std::min(grid.x, unsigned(ctx->n_cus * RT_WAVES_PER_SIMD)), 1, 1);
         RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, 256, ctx->stream));
@@ -1360,7 +1400,7 @@ int rt_get_ray_counts(rt_ctx* ctx, uint64_t out[4]) {
     const unsigned long long* h = host + s * kCounterWords;
     trace += h[0]; shade += h[1]; primary += h[2]; shadow += h[3];
   }
-  out[0] = primary;
+  out[0] = primary + ctx->host_primaries;
   out[1] = trace - primary;
   out[2] = shadow;
   out[3] = shade;
@@ -1377,6 +1417,7 @@ int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]) {
     out[k] = 0;
     for (int s = 0; s < kCounterSlots; ++s) out[k] += host[s * kCounterWords + k];
   }
+  out[0] += ctx->host_primaries; out[2] += ctx->host_primaries;
   return RT_OK;
 }
 
@@ -1384,6 +1425,7 @@ int rt_reset_ray_counts(rt_ctx* ctx) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords, ctx->stream));
+  ctx->host_primaries = 0;
   return RT_OK;
 }
 
