@@ -18,8 +18,12 @@ SRC = os.path.join(CSRC, "rt355.hip")
 HDR = os.path.join(os.path.dirname(HERE), "include", "rt355.h")
 SO = os.path.join(CSRC, "librt355.so")
 
+# -amdgpu-atomic-optimizer-strategy=None: the stream kernel keeps a lane-0 returning atomic (its next
+# work claim) in flight across a whole shading pass; LLVM's atomic optimizer would rewrite it into a
+# wave-aggregated form that reads the result back (s_waitcnt vmcnt(0)) right after issuing it.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fno-gpu-sanitize", "-Wall", "-Wno-unused-function"]
+               "-fno-gpu-sanitize", "-Wall", "-Wno-unused-function",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def needs_build() -> bool:

@@ -74,8 +74,9 @@ struct RenderParams {
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
-  int16_t* vis;            // [frame][n_rows][nx] primary hit index (-1 = miss), visibility pass -> stream kernel
-  uint8_t* tile_hits;      // [frame][tiles8_y][tiles8_x] hit pixels per 8x8 tile (same hand-over)
+  int16_t* vis;            // [frame][tiles8_y][tiles8_x][kVisTile] per 8x8 tile: 64 primary hit indices (-1 = miss /
+                           // outside the window) + header {tx | ty << 16, frame}; visibility pass -> stream kernel
+  long long vis_stride;    // elements between frames of vis
   int* chunk_counter;      // dynamic work distribution of the stream kernel (zeroed per launch)
   int tiles8_x, tiles8_y;
   uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
@@ -90,6 +91,7 @@ struct RenderParams {
 };
 
 constexpr int kBlock = 256;        // 4 waves
+constexpr int kVisTile = 72;       // int16 elements per tile record of RenderParams::vis (144 bytes)
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 cache lines
 constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shadow | 8.. phase stamps
 #if RT_STAMPS
@@ -101,10 +103,6 @@ constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (ra
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
 constexpr int kTileW = 32, kTileH = 8;
-// stream kernel: 64 x 32 pixel strip per workgroup, processed as 32 tiles of 8 x 8
-constexpr int kStripW = 64, kStripH = 32, kStripTiles = 32, kStripPix = kStripW * kStripH;
-constexpr int kQueueCap = 512;     // >= 2 * kBlock - 1
-constexpr int kQueueFields = 14;   // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1)
 
 // ------------------------------------------------------------------------------------------
 // keyed RNG — identical to oracle/ref_harness.py / oracle/rt_oracle.cpp
@@ -155,6 +153,17 @@ __device__ __forceinline__ float div_exact(float a, float b, float rb) {
 __device__ __forceinline__ int row_of(const RenderParams& p, int lr) {
   int j = lr / p.tile_rows;
   return p.y0 + (p.tile_first + j * p.tile_stride) * p.tile_rows + (lr - j * p.tile_rows);
+}
+
+// image row of window row row0 + ly, row0 a multiple of 8: wave-uniform arithmetic unless a row tile
+// is not a multiple of 8 rows (tile_rows_uniform() false)
+__device__ __forceinline__ bool tile_rows_uniform(const RenderParams& p) {
+  return p.tile_stride == 1 || (p.tile_rows & 7) == 0;
+}
+__device__ __forceinline__ int tile_row_base(const RenderParams& p, int row0) {
+  if (p.tile_stride == 1) return p.y0 + p.tile_first * p.tile_rows + row0;   // contiguous rows
+  const int j = row0 / p.tile_rows;                                          // scalar division
+  return p.y0 + (p.tile_first + j * p.tile_stride) * p.tile_rows + (row0 - j * p.tile_rows);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -410,10 +419,16 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
 #elif RT_GEOM_SRC == 2
     // wave-uniform scalar loads straight from the (constant, L2/K$-resident) geometry buffer: the
     // sphere lives in SGPRs, no LDS traffic and no VGPRs for it
-    {
+    // (software-pipelined one sphere ahead: the next s_load_dwordx4 is in flight during this
+    // sphere's 13 ray tests, and costs SGPRs only)
+    if (n > 0) {
       cgeom_t cg = as_const(gg);
-#pragma unroll 2
-      for (int i = 0; i < n; ++i) test_sphere(cg[i]);
+      float4 cur = cg[0];
+      for (int i = 0; i < n; ++i) {
+        const float4 nxt = cg[i + 1 < n ? i + 1 : i];
+        test_sphere(cur);
+        cur = nxt;
+      }
     }
 #else
 #pragma unroll 2
@@ -448,12 +463,18 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
 //     C_d = (m_d (1-r_d) + r_d C_{d+1}) * l_d   =>   acc += T * m_d (1-r_d) * l_d ;  T *= r_d * l_d
 // and produces the reflection ray (:246-247, direction not renormalised).  Returns true if the
 // path continues (r_d > 0).
-template <int MODE>
+// `load_state` is called after the lighting loops and before T / acc are touched: the stream kernel
+// keeps those (and the other fields lighting does not need) in its LDS record until then, so they
+// do not occupy registers — or scratch — across the 13 x N shadow tests.
+struct NoLateState {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int MODE, typename LateState = NoLateState>
 __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* __restrict__ sg, int idx,
                                           float px, float py, float pz, float& dx, float& dy, float& dz,
                                           uint32_t level_key, float& tr, float& tg, float& tb,
                                           float& ar, float& ag, float& ab, float& ox, float& oy,
-                                          float& oz) {
+                                          float& oz, LateState load_state = LateState()) {
   const float4 s = sg[idx];
   const float4 m = p.mat[idx];
   const float spec = p.spec[idx];
@@ -467,6 +488,7 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   float lr, lg, lb;
   lighting<MODE, kShadowBatch>(p.L, sg, p.geom, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                m.x, m.y, m.z, spec, level_key, lr, lg, lb);
+  load_state();
   const float refl = m.w;
   const float keep = 1.0f - refl;                                    // :249
   ar = fmaf(tr * (m.x * keep), lr, ar);
@@ -527,7 +549,13 @@ __device__ __forceinline__ void finish_pixel(const RenderParams& p, long long gp
     *stage_slot = rgbx;
   } else if (p.out_rgb) {   // stream kernel: only hit pixels end here, scattered over the frame
     uint8_t* o = p.out_rgb + gpix * 3;
+#if defined(RT_EXP_STORE32)
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(o) & ~uintptr_t(3)) = rgbx;   // timing experiment only
+#elif defined(RT_EXP_NOSTORE)
+    if (rgbx == 0x12345678u) o[0] = 1;
+#else
     o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
+#endif
   }
 }
 
@@ -600,28 +628,23 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
   uint32_t rgbx = 0u;                                     // hit pixels: placeholder
   if (live) {
     const rt_camera& cam = p.cams[frame];
-    int y;                                                // image row of window row row0 + ly
-    if (p.tile_stride == 1) {                             // contiguous rows (single GPU, render_chunk)
-      y = p.y0 + p.tile_first * p.tile_rows + row0 + ly;
-    } else if ((p.tile_rows & 7) == 0) {                  // the 8 rows share a row tile: scalar arithmetic
-      const int j = row0 / p.tile_rows;
-      y = p.y0 + (p.tile_first + j * p.tile_stride) * p.tile_rows + (row0 - j * p.tile_rows) + ly;
-    } else {
-      y = row_of(p, row0 + ly);
-    }
+    const int y = tile_rows_uniform(p) ? tile_row_base(p, row0) + ly : row_of(p, row0 + ly);
     uint32_t pixel_key;
     float dx, dy, dz, t;
     primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + lx, y, p.sample_index, pixel_key, dx, dy, dz);
     primary_hit(p.geom, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, cam.origin[0],
                 cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
-    p.vis[accum_px + wpix] = int16_t(idx);
     if (p.out_hit && last_sample) p.out_hit[frame_px + wpix] = idx;
     if (idx < 0)   // :237-238 miss -> black (resolves the running mean over samples too)
       finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &rgbx);
   }
-  const unsigned long long hits = __ballot(idx >= 0);
-  if (lane == 0)   // col0 < nx and row0 < n_rows here, so the tile exists
-    p.tile_hits[(size_t(frame) * p.tiles8_y + (row0 >> 3)) * p.tiles8_x + (col0 >> 3)] = uint8_t(__popcll(hits));
+  // tile-major hand-over: the 64 indices of this tile are 128 contiguous bytes; lanes outside the
+  // window write -1, so the consumer needs no bounds checks ...
+  // ... and a header names the tile, so a record is self-describing for whoever loads it
+  int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tiles8_x + (col0 >> 3)) * kVisTile;
+  rec[lane] = int16_t(idx);
+  if (lane == 0)
+    *reinterpret_cast<uint2*>(rec + 64) = make_uint2(uint32_t(col0 >> 3) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
   if (p.out_rgb && last_sample) {
     uint8_t* out = p.out_rgb + frame_px * 3;
     const bool aligned = cols == 8 && (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
@@ -645,41 +668,71 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
 }
 
 // ------------------------------------------------------------------------------------------
-// STREAM KERNEL (second half of the default path): persistent workgroups with an LDS work queue.
+// STREAM KERNEL (second half of the default path): persistent WAVES, each with its own work lists.
 //
-// The launch holds ~4 workgroups per CU; each pulls chunks (64 x 32 pixels of one frame of the
-// batch) from a global counter until none is left.  Per chunk the visibility pass has left the
-// hit sphere of every pixel and the hit count of every 8x8 tile, so only tiles with hits are
-// visited:
-//   fill phase : each of the 4 waves takes one non-empty tile, rebuilds the primary ray and hit
-//                point of its hit pixels and pushes them (wave ballot + one LDS atomic per wave)
-//                onto the workgroup's queue of records {P, D, T, acc, pixel, level|frame|sphere}.
-//   shade phase: once >= 256 records are queued (or no chunk is left) each thread pops one
-//                record: compute_lighting with its 13 x N shadow tests, throughput update,
-//                reflection ray, nearest-hit scan of that ray; a new hit goes back onto the queue,
-//                anything else finishes the pixel (3 byte stores into the frame the visibility pass
-//                has already cleared).
-// The queue lives across chunks and frames, so waves only run partially filled in the final drain
-// of a workgroup — not wherever a wave's pixels miss or die at different depths (the pixel kernel
-// below, kept for A/B evidence), and not at the end of every strip either.
+// The launch holds 4 workgroups of 4 waves per CU (4 waves per SIMD).  A workgroup only shares the
+// LDS copies of the sphere list and the batch's cameras; after the one barrier that publishes them,
+// every wave runs on its own.  Work arrives as 8x8 tiles of the frames of the batch, claimed from
+// global counters until none is left.  Per wave, in LDS:
+//   pending list : hit pixels of the tiles taken in so far — one coalesced 128-byte load of the
+//                  visibility pass's tile-major indices per tile, ballot + prefix count, 8-byte
+//                  entries {column, row, frame, sphere}.
+//   bounce queue : records {P, D, T, acc, pixel, level|frame|sphere, pixel key} of reflection rays
+//                  that hit something.
+// A shading pass takes 64 items — bounce records first, the rest from the pending list, whose
+// primary ray and hit point are rebuilt exactly as the visibility pass measured them — and per lane
+// runs compute_lighting with its 13 x N shadow tests, the throughput update, the reflection ray
+// and its nearest-hit scan; a new hit goes onto the bounce queue, anything else finishes the pixel
+// (3 byte stores into the frame the visibility pass has already cleared).  Both lists live across
+// tiles and frames, so a wave runs partially filled only in its final drain — not wherever pixels
+// miss or die at different depths (the pixel kernel below, kept for A/B evidence).  No barrier and
+// no LDS atomic sits on this path: waves drift apart, so one wave's memory-latency-bound intake
+// overlaps another's VALU-bound shading on the same SIMD.
+//
+// Work distribution.  A launch is short (a 16-frame 1080p batch: ~50 passes per wave) and the cost
+// of a tile ranges from nothing (sky) to 6 passes (64 pixels of facing mirrors), so the unit handed
+// out must be small and a wave's share must not be spatially coherent:
+//   * tile ids are dealt round-robin to kTileCounters counters on separate cache lines — counter h
+//     hands out tiles h, h + K, h + 2K, ... ("slots").  One address serves returning atomics at only
+//     ~23 ns each on this part; K addresses work in parallel, and a claim of consecutive slots is K
+//     tiles apart in the frame: decorrelated.
+//   * guided self-scheduling: a claim is 1/(2 x waves per counter) of what its counter had left,
+//     between 1 and kClaimMax slots, so private backlogs shrink towards the end of the launch.
+//   * nothing on the supply side waits for memory between two passes: the NEXT claim's atomic is in
+//     flight while the current claim is worked through, and the index data of the next kRing tiles
+//     is brought in by LDS-direct loads (global_load_lds_dword: 2 tiles = 256 bytes per instruction,
+//     no registers held across the lighting loops) issued before a pass and read after it.  A
+//     wave's first tile is its own global wave number (no atomic at the start).
+//   * a wave whose counter runs dry moves to any counter a coherent load shows not to be exhausted.
 // ------------------------------------------------------------------------------------------
+constexpr int kPendingCap = 128;                      // <= 63 left over + one tile
+constexpr int kBounceCap = 128;                       // <= 63 queued + 64 pushed
+constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
+#ifndef RT_RING
+#define RT_RING 4     // 4 keeps the kernel at 4 workgroups per CU up to 64 spheres (LDS); 8 and 16 measured no faster
+#endif
+constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
+constexpr int kWaveLdsBytes = kQueueFields * kBounceCap * 4 + kPendingCap * 8 + kRing * kVisTile * 2;
+constexpr int kTileCounters = 32;
+#ifndef RT_CLAIM
+#define RT_CLAIM 8
+#endif
+constexpr int kClaimMax = RT_CLAIM;
+
 struct Queue {
-  float* f;        // kQueueFields arrays of kQueueCap words
-  __device__ __forceinline__ float& at(int field, int i) const { return f[field * kQueueCap + i]; }
+  float* f;        // kQueueFields arrays of kBounceCap words (field-major: conflict-free lane access)
+  __device__ __forceinline__ float& at(int field, int i) const { return f[field * kBounceCap + i]; }
 };
 
-// wave-aggregated reservation of queue slots: returns this lane's slot (valid if `want`)
-__device__ __forceinline__ int queue_reserve(bool want, unsigned int* s_push, int base) {
-  const unsigned long long mask = __ballot(want);
-  const int lane = threadIdx.x & 63;
-  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-  int start = 0;
-  if (mask != 0ull) {
-    const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) start = int(atomicAdd(s_push, (unsigned int)__popcll(mask)));
-    start = __shfl(start, leader);
-  }
-  return base + start + rank;
+// LDS accesses of one wave are executed in program order; this only stops the compiler from moving
+// list reads and writes of different lanes across each other
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {   // set bits of mask below this lane
+  return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
 
 template <int MODE>
@@ -687,136 +740,210 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);
   const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
-  Queue q{reinterpret_cast<float*>(smem + geom_bytes)};
-  unsigned int* s_push = reinterpret_cast<unsigned int*>(smem + geom_bytes + kQueueFields * kQueueCap * 4);  // [3]
-  unsigned int* s_cnt = s_push + 4;                        // [2] ray statistics
-  int* s_chunk = reinterpret_cast<int*>(s_push + 6);       // [2] alternating hand-over of fetched chunk ids
-  uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_push + 8);  // [kMaxBatch]
-
+  float* s_cams = reinterpret_cast<float*>(smem + geom_bytes);                 // [kMaxBatch][12]
+  uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_cams + kMaxBatch * 12);    // [kMaxBatch]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  unsigned char* mine = reinterpret_cast<unsigned char*>(s_seeds + kMaxBatch) + wave * kWaveLdsBytes;
+  Queue q{reinterpret_cast<float*>(mine)};
+  uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kBounceCap * 4);
+  int16_t* ring = reinterpret_cast<int16_t*>(pend + kPendingCap);               // [kRing][kVisTile] tile records
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
-  if (tid < 3) s_push[tid] = 0u;
-  if (tid < 2) s_cnt[tid] = 0u;
+  if (tid < kMaxBatch * 12) s_cams[tid] = (&p.cams[0].origin[0])[tid];
   if (tid < kMaxBatch) s_seeds[tid] = p.seeds[tid];
-  __syncthreads();
+  __syncthreads();   // the only workgroup-wide synchronisation
 
-  const int strips = p.strips_x * p.strips_y;
-  const int total_chunks = strips * p.n_frames;
+  const int tiles_per_frame = p.tiles8_x * p.tiles8_y;
+  const int total_tiles = tiles_per_frame * p.n_frames;
+  const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kBlock / 64) + wave);
+  const int n_waves = int(gridDim.x) * (kBlock / 64);
   uint32_t n_trace = 0, n_shade = 0;
-  unsigned long long st_fill = 0, st_fbar = 0, st_pop = 0, st_light = 0, st_near = 0, st_sbar = 0;
+  unsigned long long st_fetch = 0, st_pop = 0, st_light = 0, st_near = 0;
   const unsigned long long st_begin = RT_NOW();
-  int q_count = 0;          // uniform across the workgroup
-  int phase = 0;            // selects the rotating push counter
-  int n_fetch = 0;
-  bool done = false;        // the chunk counter is exhausted
-  uint32_t fill_mask = 0;   // non-empty tiles of the current chunk not yet consumed
-  int frame = 0, col0 = 0, row0 = 0, cols = 0, rows = 0;
+  int n_bounce = 0, n_pend = 0;   // wave-uniform list lengths
+  bool done = false;              // no tile is left for this wave
+
+  // ---- tile supply (all wave-uniform).  Slot s of counter h is tile s * K + h; counter h has
+  // statically handed its first ceil((n_waves - h) / K) slots to the waves with number h mod K.
+  auto first_of = [&](int h) { return (n_waves - h + kTileCounters - 1) / kTileCounters; };
+  auto slots_of = [&](int h) { return (total_tiles - h + kTileCounters - 1) / kTileCounters; };
+  const int waves_per_counter2 = 2 * max(1, n_waves / kTileCounters);
+  auto claim_size = [&](int h, int slot_seen) {   // from the counter position this wave saw last
+    return max(1, min(kClaimMax, (slots_of(h) - slot_seen) / waves_per_counter2));
+  };
+  int hcur = gwave % kTileCounters;
+  uint32_t dry = 0u;               // counters this wave has seen exhausted
+  int cl_left = 0;                 // slots of the current claim not yet started
+  int cl_frame = 0, cl_ty = 0, cl_tx = 0;   // tile of the claim's next slot
+  auto decode_claim = [&](int tile_id) {    // two scalar divisions per claim; then K tiles further per slot
+    cl_frame = tile_id / tiles_per_frame;
+    const int rem = tile_id - cl_frame * tiles_per_frame;
+    cl_ty = rem / p.tiles8_x;
+    cl_tx = rem - cl_ty * p.tiles8_x;
+  };
+  if (gwave < total_tiles) { cl_left = 1; decode_claim(gwave); }
+  bool endgame = false;            // the home counter is exhausted: claims are made one tile at a time
+  int pf_n = 0, pf_c = 0;          // the claim being requested (lane 0 receives the counter value)
+  int nx_n = 0, nx_id = 0;         // the claim after the current one: slots, first tile id
+  int seen = first_of(hcur);       // position of the home counter when this wave last looked
+  // ---- ring of tiles whose index data is in LDS or on its way (FIFO: head = next to consume)
+  uint32_t head = 0, tail = 0;     // tile counts
+  bool supply_done = false;
+  unsigned long long st_topup = 0, st_wait = 0;
 
   for (;;) {
-    // ------------------------------ fill -------------------------------------------------
-    while (q_count < kBlock && !(done && fill_mask == 0u)) {
+    // ------------------------------ tile intake ------------------------------------------
+    if (n_bounce + n_pend < 64 && !done) {
       const unsigned long long s0 = RT_NOW();
-      if (fill_mask == 0u) {   // fetch the next chunk (one returning atomic per 2048 pixels)
-        if (tid == 0) s_chunk[n_fetch & 1] = atomicAdd(p.chunk_counter, 1);
-        __syncthreads();
-        const int chunk = s_chunk[n_fetch & 1];
-        ++n_fetch;
-        if (chunk >= total_chunks) {
-          done = true;
-        } else {
-          frame = chunk / strips;
-          const int strip = chunk - frame * strips;
-          const int strip_y = strip / p.strips_x, strip_x = strip - strip_y * p.strips_x;
-          col0 = strip_x * kStripW; row0 = strip_y * kStripH;       // window coordinates
-          cols = min(kStripW, p.nx - col0); rows = min(kStripH, p.n_rows - row0);
-          const int tx8 = (col0 >> 3) + (lane & 7), ty8 = (row0 >> 3) + ((lane >> 3) & 3);
-          int cnt = 0;
-          if (lane < kStripTiles && tx8 < p.tiles8_x && ty8 < p.tiles8_y)
-            cnt = p.tile_hits[(size_t(frame) * p.tiles8_y + ty8) * p.tiles8_x + tx8];
-          fill_mask = uint32_t(__ballot(cnt > 0));                   // bit t = tile (t & 7, t >> 3)
+      // Take tiles from the ring until a full pass is available, then refill the ring.  Those loads
+      // (and the next claim's atomic) fly during the coming pass, so the waits below are normally
+      // free; only when the ring runs empty inside one intake (a run of kRing tiles with few hits)
+      // is a load's latency exposed.
+      bool consuming = true;
+      for (;;) {
+        if (head == tail || !consuming) {
+          // ---- refill: one tile per turn while the ring has room.  When the current claim will not
+          // outlast this refill the next one is requested FIRST, so its round trip overlaps the
+          // tile loads issued below; it is read back at the end of the refill (the compiler would
+          // wait for it there anyway: it does not leave a returning atomic's register alone across
+          // the pass).
+          const unsigned long long t0 = RT_NOW();
+          for (;;) {
+            bool asked = false;
+            if (nx_n == 0 && !endgame && cl_left < kRing) {
+              pf_n = claim_size(hcur, seen);
+              if (lane == 0) pf_c = atomicAdd(p.chunk_counter + hcur * 32, pf_n);
+              asked = true;
+            }
+            bool stalled = false;              // the ring has room but the next claim has not landed
+            while (tail - head < uint32_t(kRing) && !supply_done) {
+              if (cl_left == 0) {
+                if (nx_n > 0) { cl_left = nx_n; nx_n = 0; decode_claim(nx_id); continue; }
+                if (!endgame) { stalled = true; break; }
+                // endgame: look (coherently) for a counter that still has tiles, claim one synchronously
+                int next = total_tiles;
+                if (lane < kTileCounters)
+                  next = (__hip_atomic_load(p.chunk_counter + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                          first_of(lane)) * kTileCounters + lane;
+                const uint32_t avail = uint32_t(__ballot(next < total_tiles)) & ~dry;
+                if (avail == 0u) { supply_done = true; break; }
+                const uint32_t from = avail >> hcur;    // first candidate at or after hcur
+                hcur = from ? hcur + __ffs(int(from)) - 1 : __ffs(int(avail)) - 1;
+                int c2 = 0;
+                if (lane == 0) c2 = atomicAdd(p.chunk_counter + hcur * 32, 1);
+                c2 = __builtin_amdgcn_readfirstlane(c2);
+                const int id = (first_of(hcur) + c2) * kTileCounters + hcur;
+                if (id < total_tiles) { cl_left = 1; decode_claim(id); }
+                else dry |= 1u << hcur;
+                continue;
+              }
+              if (cl_frame >= p.n_frames) { cl_left = 0; continue; }   // the rest of this claim lies beyond the end
+              // ---- issue the tile: 36 lanes x 4 bytes (indices + header) straight into ring[slot]
+              const uint32_t slot = tail & uint32_t(kRing - 1);
+              if (lane < kVisTile / 2)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(
+                        p.vis + (size_t)cl_frame * p.vis_stride + ((size_t)cl_ty * p.tiles8_x + cl_tx) * kVisTile + lane * 2),
+                    (__attribute__((address_space(3))) void*)(ring + slot * kVisTile), 4, 0, 0);
+              ++tail;
+              --cl_left;
+              cl_tx += kTileCounters;
+              while (cl_tx >= p.tiles8_x) { cl_tx -= p.tiles8_x; ++cl_ty; }
+              while (cl_ty >= p.tiles8_y) { cl_ty -= p.tiles8_y; ++cl_frame; }
+            }
+            if (asked) {                       // read the claim back
+              const int slot = first_of(hcur) + __builtin_amdgcn_readfirstlane(pf_c);
+              seen = slot + pf_n;
+              if (slot * kTileCounters + hcur < total_tiles) { nx_n = pf_n; nx_id = slot * kTileCounters + hcur; }
+              else { endgame = true; dry |= 1u << hcur; }
+            }
+            if (!stalled) break;               // else: go round again with the claim that has just landed
+          }
+          st_topup += RT_NOW() - t0;
+          if (!consuming) break;
+          if (head == tail) { done = true; break; }   // nothing left anywhere
         }
-        st_fbar += RT_NOW() - s0;
-        continue;
-      }
-      unsigned int* push = s_push + (phase % 3);
-      if (tid == 0) s_push[(phase + 1) % 3] = 0u;
-      // the next four non-empty tiles, one per wave
-      int tile = -1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (fill_mask != 0u) {
-          if (j == wave) tile = __ffs(int(fill_mask)) - 1;
-          fill_mask &= fill_mask - 1u;
+        // ---- consume one tile
+        const unsigned long long w0 = RT_NOW();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-direct loads are not tracked by the compiler
+        st_wait += RT_NOW() - w0;
+        const uint32_t slot = head & uint32_t(kRing - 1);
+        ++head;
+        const int idx = ring[slot * kVisTile + lane];
+        const unsigned long long mask = __ballot(idx >= 0);
+        if (mask != 0ull) {                                  // else: empty tile (sky)
+          const uint2 m = *reinterpret_cast<const uint2*>(ring + slot * kVisTile + 64);   // the record's header
+          const uint32_t m0 = __builtin_amdgcn_readfirstlane(m.x), m1 = __builtin_amdgcn_readfirstlane(m.y);
+          const uint32_t col = (m0 & 0xFFFFu) * 8u + uint32_t(lane & 7), row = (m0 >> 16) * 8u + uint32_t(lane >> 3);
+          if (idx >= 0)                  // entry: column | frame << 24,  row | sphere << 20
+            pend[n_pend + lanes_below(mask)] = make_uint2(col | (m1 << 24), row | (uint32_t(idx) << 20));
+          n_pend += __popcll(mask);
         }
+        if (n_bounce + n_pend >= 64) consuming = false;      // one more turn: refill, then shade
       }
+      wave_lds_fence();
+      st_fetch += RT_NOW() - s0;
+      continue;
+    }
+    if (n_bounce + n_pend == 0) break;
+
+    // ------------------------------ shading pass -----------------------------------------
+    {
+      const unsigned long long s0 = RT_NOW();
+      const int nb = min(64, n_bounce), base = n_bounce - nb;       // bounce records: lanes [0, nb)
+      const int np = min(64 - nb, n_pend), base_p = n_pend - np;    // pending hits:   lanes [nb, nb + np)
+      const bool have = lane < nb + np;
+      // Lane l works on record slot e = base + l.  Only what the lighting loops need comes into
+      // registers now (P, D, meta, key); T, acc and the pixel stay in the slot until after them.
+      const int e = base + lane;
       float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-      int idx = -1;
-      const int lx = (tile & 7) * 8 + (lane & 7), ly = (tile >> 3) * 8 + (lane >> 3);
-      const uint32_t wpix = uint32_t(row0 + ly) * uint32_t(p.nx) + uint32_t(col0 + lx);
-      if (tile >= 0 && lx < cols && ly < rows) idx = p.vis[(long long)frame * p.accum_stride_px + wpix];
-      const bool hit = idx >= 0;
-      if (hit) {
+      uint32_t meta = 0, pixel_key = 0;
+      if (lane < nb) {
+        px = q.at(0, e); py = q.at(1, e); pz = q.at(2, e);
+        dx = q.at(3, e); dy = q.at(4, e); dz = q.at(5, e);
+        meta = __float_as_uint(q.at(13, e));
+        pixel_key = __float_as_uint(q.at(14, e));
+      } else if (have) {
+        const uint2 pe = pend[base_p + lane - nb];
+        const int col = int(pe.x & 0xFFFFFu), frame = int(pe.x >> 24);
+        const int row = int(pe.y & 0xFFFFFu), idx = int(pe.y >> 20);
+        const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
+        rt_camera cam;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) (&cam.origin[0])[k] = s_cams[frame * 12 + k];
         // rebuild the primary ray and its hit point exactly as the visibility pass measured them
-        const rt_camera& cam = p.cams[frame];
-        const int x = p.x0 + col0 + lx, y = row_of(p, row0 + ly);
-        uint32_t pixel_key;
-        primary_ray<MODE>(p, cam, s_seeds[frame], x, y, p.sample_index, pixel_key, dx, dy, dz);
+        primary_ray<MODE>(p, cam, s_seeds[frame], p.x0 + col, y, p.sample_index, pixel_key, dx, dy, dz);
         const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
         float dl;
         const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
         px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
-      }
-      const int slot = queue_reserve(hit, push, q_count);
-      if (hit) {
-        q.at(0, slot) = px; q.at(1, slot) = py; q.at(2, slot) = pz;
-        q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
-        q.at(6, slot) = 1.f; q.at(7, slot) = 1.f; q.at(8, slot) = 1.f;
-        q.at(9, slot) = 0.f; q.at(10, slot) = 0.f; q.at(11, slot) = 0.f;
-        q.at(12, slot) = __uint_as_float(wpix);
         // meta: level (8 bits) | frame (8 bits) | sphere index (16 bits)
-        q.at(13, slot) = __uint_as_float(0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16));
+        meta = 0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16);
+        // a fresh level-0 record: T = 1, acc = 0 (slots [base + nb, base + 64) are free)
+        q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;
+        q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f;
+        q.at(12, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
+        q.at(14, e) = __uint_as_float(pixel_key);
       }
-      const unsigned long long s1 = RT_NOW();
-      __syncthreads();
-      st_fill += s1 - s0; st_fbar += RT_NOW() - s1;
-      q_count += int(*push);
-      ++phase;
-    }
-    if (q_count == 0) break;
-
-    // ------------------------------ shade ------------------------------------------------
-    {
-      const unsigned long long s0 = RT_NOW();
-      unsigned int* push = s_push + (phase % 3);
-      if (tid == 0) s_push[(phase + 1) % 3] = 0u;
-      const int n_pop = min(kBlock, q_count);
-      const int base = q_count - n_pop;
-      const bool have = tid < n_pop;
-      float px, py, pz, dx, dy, dz, tr, tg, tb, ar, ag, ab;
-      uint32_t wpix = 0, meta = 0;
-      if (have) {
-        const int e = base + tid;
-        px = q.at(0, e); py = q.at(1, e); pz = q.at(2, e);
-        dx = q.at(3, e); dy = q.at(4, e); dz = q.at(5, e);
-        tr = q.at(6, e); tg = q.at(7, e); tb = q.at(8, e);
-        ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e);
-        wpix = __float_as_uint(q.at(12, e));
-        meta = __float_as_uint(q.at(13, e));
-      }
-      __syncthreads();   // every record of this batch is in registers before slots are reused
+      n_pend = base_p;
+      wave_lds_fence();
       const unsigned long long s1 = RT_NOW();
       unsigned long long s2 = s1;
       bool again = false;
+      float tr = 1.f, tg = 1.f, tb = 1.f, ar = 0.f, ag = 0.f, ab = 0.f;
+      uint32_t wpix = 0;
+      auto late_state = [&]() {
+        tr = q.at(6, e); tg = q.at(7, e); tb = q.at(8, e);
+        ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e);
+        wpix = __float_as_uint(q.at(12, e));
+        pixel_key = __float_as_uint(q.at(14, e));
+      };
       if (have) {
         const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
-        const int prow = int(wpix / uint32_t(p.nx)), pcol = int(wpix - uint32_t(prow) * uint32_t(p.nx));
-        const int x = p.x0 + pcol, y = row_of(p, prow);
-        const uint32_t pixel_key =
-            mix(mix(mix(s_seeds[rframe], uint32_t(x)), uint32_t(y)), uint32_t(p.sample_index));
         ++n_shade;
         float ox, oy, oz;
-        bool cont = shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, mix(pixel_key, uint32_t(level + 1)),
-                                    tr, tg, tb, ar, ag, ab, ox, oy, oz);
+        const uint32_t level_key = mix(pixel_key, uint32_t(level + 1));
+        bool cont = shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, level_key,
+                                    tr, tg, tb, ar, ag, ab, ox, oy, oz, late_state);
         cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
         s2 = RT_NOW();
         if (cont) {
@@ -834,36 +961,49 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           finish_pixel(p, (long long)rframe * p.frame_stride_px + wpix,
                        (long long)rframe * p.accum_stride_px + wpix, ar, ag, ab, nullptr);
       }
-      const int slot = queue_reserve(again, push, base);
+      wave_lds_fence();   // every lane has its whole record in registers before slots are rewritten
+      const unsigned long long mask = __ballot(again);
       if (again) {
+        const int slot = base + lanes_below(mask);
         q.at(0, slot) = px; q.at(1, slot) = py; q.at(2, slot) = pz;
         q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
         q.at(6, slot) = tr; q.at(7, slot) = tg; q.at(8, slot) = tb;
         q.at(9, slot) = ar; q.at(10, slot) = ag; q.at(11, slot) = ab;
         q.at(12, slot) = __uint_as_float(wpix);
         q.at(13, slot) = __uint_as_float(meta);
+        q.at(14, slot) = __uint_as_float(pixel_key);
       }
+      n_bounce = base + __popcll(mask);
+      wave_lds_fence();
       const unsigned long long s3 = RT_NOW();
-      __syncthreads();
-      st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2; st_sbar += RT_NOW() - s3;
-      q_count = base + int(*push);
-      ++phase;
+      st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
     }
   }
 
-  // ---- ray statistics ---------------------------------------------------------------------------
-  if (n_trace) atomicAdd(&s_cnt[0], n_trace);
-  if (n_shade) atomicAdd(&s_cnt[1], n_shade);
-  __syncthreads();
-  if (tid == 0 && p.counters) flush_counters(p, s_cnt, blockIdx.x, 0ull);   // primaries: visibility pass
+  // ---- ray statistics (per wave; primaries are the visibility pass's) -----------------------------
+  if (p.counters) {
+    unsigned long long tot_t = n_trace, tot_s = n_shade;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      tot_t += __shfl_xor(tot_t, o);
+      tot_s += __shfl_xor(tot_s, o);
+    }
+    if (lane == 0) {
+      unsigned long long* slot = p.counters + size_t(gwave % kCounterSlots) * kCounterWords;
+      if (tot_t) atomicAdd(slot + 0, tot_t);
+      if (tot_s) {
+        atomicAdd(slot + 1, tot_s);
+        atomicAdd(slot + 3, tot_s * (unsigned long long)(1 + p.L.ns));
+      }
 #if RT_STAMPS
-  if (lane == 0 && p.counters) {   // per-wave phase sums (diagnostic build only; read by tools/stamps.py)
-    unsigned long long* slot = p.counters + size_t(blockIdx.x % kCounterSlots) * kCounterWords + 8;
-    atomicAdd(slot + 0, st_fill); atomicAdd(slot + 1, st_fbar); atomicAdd(slot + 2, st_pop);
-    atomicAdd(slot + 3, st_light); atomicAdd(slot + 4, st_near); atomicAdd(slot + 5, st_sbar);
-    atomicAdd(slot + 6, RT_NOW() - st_begin); atomicAdd(slot + 7, 1ull);
-  }
+      // per-wave phase sums (diagnostic build only; read by tools/stamps.py)
+      atomicMax(slot + 8, RT_NOW() - st_begin); atomicAdd(slot + 9, st_fetch); atomicAdd(slot + 10, st_pop);
+      atomicAdd(slot + 11, st_light); atomicAdd(slot + 12, st_near); atomicAdd(slot + 13, st_topup);
+      atomicAdd(slot + 7, st_wait);
+      atomicAdd(slot + 14, RT_NOW() - st_begin); atomicAdd(slot + 15, 1ull);
 #endif
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -972,8 +1112,7 @@ struct rt_ctx {
   unsigned long long* d_counters = nullptr;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][RT_MAX_SPHERES / 4] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
-  uint8_t* d_tile_hits = nullptr;  // [batch][8x8 tiles of the window]
-  int* d_chunk = nullptr;        // stream kernel's chunk counter (64 ints, only [0] used)
+  int* d_chunk = nullptr;        // stream kernel's chunk counters (kTileCounters, one per 128-byte line)
   size_t vis_elems = 0;
   int n_cus = 256;
   float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
@@ -1006,7 +1145,7 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
 size_t stream_lds(int n_spheres) {
-  return geom_lds(n_spheres) + size_t(kQueueFields) * kQueueCap * 4 + 32 + 4 * kMaxBatch + 16;
+  return geom_lds(n_spheres) + size_t(kMaxBatch) * 13 * 4 + size_t(kWaveLdsBytes) * (kBlock / 64);
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -1067,15 +1206,12 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   if (stream_kernel) {  // primary-hit indices handed from the visibility pass to the stream kernel
-    const size_t need = size_t(win_px) * size_t(batch);
+    const size_t need = size_t((w.nx + 7) / 8) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles
     if (need > ctx->vis_elems) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_vis) RT_HIP(ctx, hipFree(ctx->d_vis));
-      if (ctx->d_tile_hits) RT_HIP(ctx, hipFree(ctx->d_tile_hits));
-      ctx->d_vis = nullptr; ctx->d_tile_hits = nullptr; ctx->vis_elems = 0;
+      ctx->d_vis = nullptr; ctx->vis_elems = 0;
       RT_HIP(ctx, hipMalloc(&ctx->d_vis, need * sizeof(int16_t)));
-      // an 8x8 tile grid never has more tiles than pixels / 8 + rows + cols
-      RT_HIP(ctx, hipMalloc(&ctx->d_tile_hits, need / 8 + size_t(batch) * size_t(w.nx + w.n_rows + 8)));
       ctx->vis_elems = need;
     }
   }
@@ -1094,15 +1230,15 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
   p.vis = ctx->d_vis;
-  p.tile_hits = ctx->d_tile_hits;
   p.chunk_counter = ctx->d_chunk;
   p.tiles8_x = (w.nx + 7) / 8; p.tiles8_y = (w.n_rows + 7) / 8;
   p.counters = ctx->d_counters;
   p.frame_stride_px = frame_px;
   p.accum_stride_px = win_px;
+  p.vis_stride = (long long)p.tiles8_x * p.tiles8_y * kVisTile;
   unsigned per_frame;
   if (stream_kernel) {
-    p.strips_x = (w.nx + kStripW - 1) / kStripW; p.strips_y = (w.n_rows + kStripH - 1) / kStripH;
+    p.strips_x = p.tiles8_x; p.strips_y = p.tiles8_y;   // work units of the stream kernel: 8x8 tiles
     per_frame = unsigned(p.strips_x) * unsigned(p.strips_y);
   } else {
     per_frame = unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH);
@@ -1138,8 +1274,9 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         const size_t vlds = 0;
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
-        const dim3 sgrid(std::min(grid.x, unsigned(ctx->n_cus * RT_WAVES_PER_SIMD)), 1, 1);
-        RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, 256, ctx->stream));
+        const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus * RT_WAVES_PER_SIMD)), 1, 1);
+        static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, kTileCounters * 128, ctx->stream));
         if (rng_mode == RT_RNG_KEYED) {
           hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_KEYED>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
           hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_KEYED>, sgrid, dim3(kBlock), lds, ctx->stream, p);
@@ -1205,7 +1342,7 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * (RT_MAX_SPHERES / 4) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_chunk, 256)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_chunk, kTileCounters * 128)) != hipSuccess) return bail(e, "hipMalloc");
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMalloc");
@@ -1232,7 +1369,6 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);
-  if (ctx->d_tile_hits) (void)hipFree(ctx->d_tile_hits);
   if (ctx->d_chunk) (void)hipFree(ctx->d_chunk);
   delete ctx;
 }

@@ -17,9 +17,14 @@ for it in range(2):
     r.render_frames([Camera()] * F, range(F), w, h, 1, max_depth=D)
 a = (ctypes.c_uint64 * 16)()
 r._check(r._L.rt_debug_counters(r._h, a))
-names = ["fill work", "fill barrier", "pop+barrier", "lighting", "reflect scan+push", "shade barrier"]
+# word 8 holds a per-slot atomicMax of the wave lifetime; rt_debug_counters sums the 64 slots, so it
+# is an upper bound of 64 x the longest wave: print the mean of the slot maxima
+print(f"mean over counter slots of the longest wave lifetime: {a[8] / 64:.0f} clk")
+a[8] = 0
+names = ["(max lifetime)", "tile intake", "pop + primary rebuild", "lighting", "reflect scan+push", "(of intake: top_up)"]
 tot = a[14]
 print(f"{desc}: {a[15]} waves, mean wave lifetime {tot / max(a[15], 1):.0f} clk")
 for i, nm in enumerate(names):
     print(f"  {nm:20s} {100.0 * a[8 + i] / max(tot, 1):6.2f} %")
+print(f"  (of intake: vmcnt wait) {100.0 * a[7] / max(tot, 1):6.2f} %")
 print(f"  {'other (setup/store)':20s} {100.0 * (tot - sum(a[8:14])) / max(tot, 1):6.2f} %")

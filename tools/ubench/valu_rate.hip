@@ -86,6 +86,14 @@ DEF_KERNEL(k_fma_neg, "v_fma_f32 %0, -%0, %1, %2")
 DEF_KERNEL(k_maxabs, "v_max_f32 %0, -|%0|, %1")
 DEF_KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 1, %1")
 DEF_KERNEL(k_xor, "v_xor_b32 %0, %0, %1")
+DEF_KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8")
+DEF_KERNEL(k_sub, "v_sub_f32 %0, %0, %1")
+DEF_KERNEL(k_cvt, "v_cvt_f32_u32 %0, %0")
+DEF_KERNEL(k_sdwa, "v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD")
+DEF_KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
+DEF_KERNEL(k_lshr, "v_lshrrev_b32 %0, 13, %0")
+DEF_KERNEL(k_fma_lit, "v_fma_f32 %0, 2.0, %1, %0")
+DEF_KERNEL(k_fmac_lit, "v_fmac_f32 %0, 0x36800000, %1")
 
 template <typename K>
 double run(K kern, int waves_per_simd, int iters, float* d) {
@@ -109,6 +117,7 @@ int main() {
   RUN("v_min_f32", k_min) RUN("v_max_f32", k_max) RUN("v_mul_f32", k_mul) RUN("v_add_f32", k_add) RUN("v_fmac_f32", k_fmac)
   RUN("v_med3_f32", k_med3) RUN("v_cmp_lt", k_cmp) RUN("v_cndmask", k_cndmask) RUN("v_and_b32", k_and) RUN("v_mul_lo_u32", k_mullo)
   RUN("v_sqrt_f32", k_sqrt) RUN("v_rsq_f32", k_rsq) RUN("v_fma neg", k_fma_neg) RUN("v_max -|x|", k_maxabs) RUN("v_lshl_add", k_lshl_add) RUN("v_xor", k_xor)
+  RUN("v_bitop3", k_bitop3) RUN("v_sub_f32", k_sub) RUN("v_cvt_f32_u32", k_cvt) RUN("v_xor sdwa", k_sdwa) RUN("v_xad_u32", k_xad) RUN("v_lshrrev", k_lshr) RUN("v_fma 2.0", k_fma_lit) RUN("v_fmac literal", k_fmac_lit)
   for (int w : {1, 2, 3, 4, 8}) {
     double ms = run(k_fma<8>, w, iters, d);
     printf("v_fma_f32     8  %d  %.3f  %.1f\n", w, ms, double(iters) * 8 * 8 * w / (ms * 1e3));
