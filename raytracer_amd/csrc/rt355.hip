@@ -240,27 +240,27 @@ typedef const CamGroup* camtab_t;
 __device__ __forceinline__ camtab_t as_const(const CamGroup* p) { return p; }
 #endif
 
+// groups of a frame's table: the sphere groups rounded up to an even count (the scan below is
+// unrolled by two) plus one never-hit group for its last, unused, prefetch
+__host__ __device__ __forceinline__ int cam_groups_scanned(int n) { return (((n + 3) >> 2) + 1) & ~1; }
+__host__ __device__ __forceinline__ int cam_groups_stride(int n) { return cam_groups_scanned(n) + 1; }
+
 __device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
                                             int n, float ox, float oy, float oz, float dx, float dy,
                                             float dz, float& best_t, int& best_i) {
   best_t = INFINITY;
   best_i = -1;
-  const int ngroups = (n + 3) >> 2;   // the table is padded with never-hit entries
+  const int ngroups = cam_groups_scanned(n);   // padded with never-hit entries
   camtab_t tab = as_const(camtab);
   cgeom_t geom = as_const(gg);   // candidates are rare: their sphere comes by scalar load
   const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-  if (ngroups == 0) return;
-  CamGroup cur = tab[0];
-  for (int g = 0; g < ngroups; ++g) {
-    // the next group's scalar load is issued before this group's arithmetic and its (rare)
-    // candidate branch, so its latency is covered instead of being paid once per group
-    const CamGroup nxt = tab[g + 1 < ngroups ? g + 1 : g];
+  auto test_group = [&](const CamGroup& grp, int g) {
     float nb[4], disc[4];
     uint32_t any = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      nb[j] = fmaf(cur.z[j], dz, fmaf(cur.y[j], dy, cur.x[j] * dx));
-      disc[j] = fmaf(nb[j], nb[j], cur.negc[j]);
+      nb[j] = fmaf(grp.z[j], dz, fmaf(grp.y[j], dy, grp.x[j] * dx));
+      disc[j] = fmaf(nb[j], nb[j], grp.negc[j]);
       any &= __float_as_uint(disc[j]) | __float_as_uint(nb[j]);
     }
     if (int(any) >= 0) {
@@ -270,7 +270,7 @@ __device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const
       for (int j = 0; j < 4; ++j) {
         if (disc[j] >= 0.0f && nb[j] > 0.0f) {
           float dl;
-          const float t = sphere_t_exact(geom[min(4 * g + j, n - 1)], ox, oy, oz, dx, dy, dz, inv_a, dl);
+          const float t = sphere_t_exact(geom[4 * g + j], ox, oy, oz, dx, dy, dz, inv_a, dl);
           if (dl >= 0.0f && t > 0.0f && t < best_t) {
             best_t = t;
             best_i = 4 * g + j;
@@ -278,7 +278,15 @@ __device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const
         }
       }
     }
-    cur = nxt;
+  };
+  // Two groups per turn in two SGPR sets (no register-to-register rotation); each group's scalar
+  // load is issued one group ahead of its arithmetic and the (rare) candidate branch.
+  CamGroup a = tab[0];
+  for (int g = 0; g < ngroups; g += 2) {
+    const CamGroup b = tab[g + 1];
+    test_group(a, g);
+    a = tab[g + 2];
+    test_group(b, g + 1);
   }
 }
 
@@ -292,7 +300,7 @@ struct CamBatch {
 __global__ __launch_bounds__(256) void rt_camera_table_kernel(const float4* __restrict__ geom, int n,
                                                               const CamBatch cb,
                                                               CamGroup* __restrict__ camtab, int n_frames) {
-  const int n4 = (n + 3) & ~3;
+  const int n4 = cam_groups_stride(n) * 4;   // every entry of the padded table is written
   const int frame = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4 || frame >= n_frames) return;
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
     uint32_t pixel_key;
     float dx, dy, dz, t;
     primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + lx, y, p.sample_index, pixel_key, dx, dy, dz);
-    primary_hit(p.geom, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, cam.origin[0],
+    primary_hit(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
                 cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     if (p.out_hit && last_sample) p.out_hit[frame_px + wpix] = idx;
     if (idx < 0)   // :237-238 miss -> black (resolves the running mean over samples too)
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_pixel_kernel(con
       int idx;
       ++n_trace;
       if (level == 0)
-        primary_hit(p.geom, p.camtab + size_t(frame) * ((p.n_spheres + 3) >> 2), p.n_spheres, ox, oy, oz, dx, dy,
+        primary_hit(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, ox, oy, oz, dx, dy,
                     dz, t, idx);
       else
         nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx);
@@ -1110,7 +1118,7 @@ struct rt_ctx {
   float4* d_mat = nullptr;
   float* d_spec = nullptr;
   unsigned long long* d_counters = nullptr;
-  CamGroup* d_camtab = nullptr;  // [kMaxBatch][RT_MAX_SPHERES / 4] primary-ray tables
+  CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
   int* d_chunk = nullptr;        // stream kernel's chunk counters (kTileCounters, one per 128-byte line)
   size_t vis_elems = 0;
@@ -1259,8 +1267,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     {  // primary-ray tables of this batch (stream order protects the previous batch's readers)
       CamBatch cb;
       for (int f = 0; f < nf; ++f) memcpy(cb.origin[f], cams[f0 + f].origin, sizeof cb.origin[f]);
-      const int n4 = (ctx->n_spheres + 3) & ~3;
-      if (n4 > 0) {
+      const int n4 = cam_groups_stride(ctx->n_spheres) * 4;
+      {
         hipLaunchKernelGGL(rt_camera_table_kernel, dim3(unsigned((n4 + 255) / 256), unsigned(nf), 1), dim3(256),
                            0, ctx->stream, (const float4*)ctx->d_geom, ctx->n_spheres, cb, ctx->d_camtab, nf);
         RT_HIP(ctx, hipGetLastError());
@@ -1337,10 +1345,10 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
   ctx->stream = ctx->own_stream;
-  if ((e = hipMalloc(&ctx->d_geom, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_geom, sizeof(float4) * (RT_MAX_SPHERES + 8))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_mat, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * (RT_MAX_SPHERES / 4) * kMaxBatch)) != hipSuccess)
+  if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_chunk, kTileCounters * 128)) != hipSuccess) return bail(e, "hipMalloc");
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
