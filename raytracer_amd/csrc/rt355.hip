@@ -29,6 +29,9 @@
 #ifndef RT_NEAR_SRC
 #define RT_NEAR_SRC 2     // reflection-ray scan reads spheres from: 0 LDS, 2 scalar loads
 #endif
+#ifndef RT_CULL
+#define RT_CULL 1         // shadow scan: per-lane cone culling of spheres (0 = every sphere for every lane)
+#endif
 #ifndef RT_STAMPS
 #define RT_STAMPS 0       // diagnostic build: per-phase s_memtime sums into counters[.][8..15]
 #endif
@@ -51,6 +54,7 @@ struct DevLights {
   float ppos[3], pcol[3], pint;
   float apos[3], au[3], av[3], acol[3], aint;
   int ns;
+  float arad;   // 0.5 (|au| + |av|): every area-light sample lies within this distance of apos
 };
 
 constexpr int kMaxBatch = 16;  // frames per launch
@@ -331,6 +335,15 @@ __global__ __launch_bounds__(256) void rt_camera_table_kernel(const float4* __re
 // m_k >= 0).  L is a unit vector (a = 1 +- 2e-7): the residual of q = nb along L enters |l|^2 only
 // to second order.
 // ------------------------------------------------------------------------------------------
+#if RT_STAMPS
+static __device__ unsigned long long g_dbg[4];
+#define g_dbg_rel dbg_rel_
+#define g_dbg_lanes dbg_lanes_
+#define g_dbg_iters dbg_iters_
+static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigned i) {
+  atomicAdd(&g_dbg[0], (unsigned long long)r); atomicAdd(&g_dbg[1], (unsigned long long)l); atomicAdd(&g_dbg[2], (unsigned long long)i);
+}
+#endif
 template <int MODE, int B>
 __device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg,
                                          const float4* __restrict__ gg, int n,
@@ -338,6 +351,9 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          float mr, float mg, float mb, float spec, uint32_t level_key,
                                          float& lr, float& lg, float& lb) {
+#if RT_STAMPS
+  unsigned dbg_rel_ = 0, dbg_lanes_ = 0, dbg_iters_ = 0;
+#endif
   const int nrays = 1 + L.ns;
   const float vdn = -(fmaf(dz, nz, fmaf(dy, ny, dx * nx)));  // view . normal, view = -D (:257)
   float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
@@ -409,7 +425,71 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
         }
       }
     };
-#if RT_GEOM_SRC == 1
+#if RT_CULL
+    // Per-lane sphere culling.  The B rays of a lane leave one point towards one small light, so
+    // almost every sphere is far from all of them; but lanes of a wave are unrelated pixels, so no
+    // sphere can be skipped for the whole wave.  Instead each lane first collects, 32 spheres at
+    // a time, a bit mask of the spheres that can matter to it (~20 ops per sphere instead of
+    // 7 B + 11) and then the wave loops max-over-lanes(popcount) times, every lane testing ITS next
+    // candidate, fetched from LDS by per-lane index.  A sphere can matter to a lane if
+    //   * the shadow origin is outside it (c > 0; inside: the near root is negative, :102), and
+    //   * it reaches into the cone {apex S, axis towards the light's centre, half-angle
+    //     asin(R / |A - P|)} that holds every area-light ray (R bounds the light's half extent; the
+    //     test  perp cos(t) - along sin(t) <= r  carries ~0.4 % of slack, far above FP32 error), or
+    //   * (first batch) the point-light ray's plain discriminant says "hit or too close to call" —
+    //     exactly tier 1's own condition for touching the verdict of ray 0.
+    // A culled sphere would have left every verdict as it was, so results are unchanged.
+    {
+      const float ax0 = L.apos[0] - px, ay0 = L.apos[1] - py, az0 = L.apos[2] - pz;
+      const float dA2 = fmaf(az0, az0, fmaf(ay0, ay0, ax0 * ax0));
+      const float inv_dA = frsq(dA2);
+      const float axx = ax0 * inv_dA, axy = ay0 * inv_dA, axz = az0 * inv_dA;
+      const float sin_t = fminf(1.0f, L.arad * inv_dA * 1.00390625f);
+      const float cos2_t = fmaf(-sin_t, sin_t, 1.0f);
+      const float sin2_t = sin_t * sin_t * 1.0078125f;
+      const bool wide = !(sin_t < 0.99f);   // P within (about) the light's bounding sphere: rays go anywhere
+      for (int cbase = 0; cbase < n; cbase += 32) {
+        const int cn = min(32, n - cbase);
+        uint32_t rel = 0u;
+        for (int j = cn - 1; j >= 0; --j) {   // (downwards: each verdict is shifted in at bit 0)
+          const float4 g = sg[cbase + j];   // wave-uniform address: LDS broadcast
+          const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
+          const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
+          const float d2 = c + g.w, r = fsqrt(g.w);
+          const float along = fmaf(cz, axz, fmaf(cy, axy, cx * axx));
+          const float al2 = along * along, perp2 = d2 - al2;
+          // sign bits do the logic (full-rate bit ops instead of half-rate compares): a set sign = "no"
+          //   rhs < 0 or rhs^2 < perp^2 cos^2 : out of the cone's reach
+          //   along < 0 and along^2 cos^2 > perp^2 sin^2 : every ray of the cone points away (nb < 0)
+          const float rhs = fmaf(along, sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
+          const float t2 = fmaf(rhs, rhs, -(perp2 * cos2_t));
+          const float e = fmaf(al2, cos2_t, -(perp2 * sin2_t));
+          uint32_t no = __float_as_uint(rhs) | __float_as_uint(t2) | (__float_as_uint(along) & ~__float_as_uint(e));
+          if (wide) no = 0u;
+          if (base == 0) {   // the point-light ray (k = 0): nb > 0 and nb^2 - c + 1.5 thr >= 0
+            const float nb = fmaf(cz, Lz[0], fmaf(cy, Ly[0], cx * Lx[0]));
+            const float q = fmaf(nb, nb, fmaf(d2, 1.5f / 262144.0f, -c));   // tier 1 acts on nb^2 - c + 2^-18 d2 >= 0
+            no &= __float_as_uint(nb) | __float_as_uint(q);
+          }
+          no |= __float_as_uint(c);           // origin inside the sphere: never hit
+          rel = __builtin_amdgcn_alignbit(rel, ~no, 31);   // rel = rel << 1 | (sign clear)
+        }
+#if RT_STAMPS
+        g_dbg_rel += __popc(rel); g_dbg_lanes += 1;
+#endif
+        while (__ballot(rel != 0u) != 0ull) {
+#if RT_STAMPS
+          g_dbg_iters += 1;
+#endif
+          if (rel != 0u) {
+            const int j = __ffs(int(rel)) - 1;
+            rel &= rel - 1u;
+            test_sphere(sg[cbase + j]);
+          }
+        }
+      }
+    }
+#elif RT_GEOM_SRC == 1
     // LDS broadcast reads, software-pipelined one pair of spheres ahead so the ds_read latency is
     // covered by the previous pair's 26 ray tests
     {
@@ -456,6 +536,9 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
       } else { ad += wd; as += ws; }
     }
   }
+#if RT_STAMPS
+  dbg_flush(dbg_rel_, dbg_lanes_, dbg_iters_);
+#endif
   if (!(spec > 0.0f)) { ps = 0.f; as = 0.f; }                        // :191 / :206
   // :204 + :209 + :189/:194/:196
   const float inv_ns = 1.0f / float(L.ns);
@@ -1439,6 +1522,8 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
   memcpy(L.acol, lights->area_color, 12);
   L.aint = lights->area_intensity; L.ns = lights->area_samples;
+  L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
+                   std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
   ctx->n_spheres = n_spheres;
   return RT_OK;
 }
@@ -1562,6 +1647,15 @@ int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]) {
     for (int s = 0; s < kCounterSlots; ++s) out[k] += host[s * kCounterWords + k];
   }
   out[0] += ctx->host_primaries; out[2] += ctx->host_primaries;
+#if RT_STAMPS
+  {  // culling statistics: [4] candidate spheres summed over lanes, [5] lane-chunks, [6] drain-loop turns summed over lanes
+    unsigned long long h[4];
+    RT_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h));
+    out[4] = h[0]; out[5] = h[1]; out[6] = h[2];
+    unsigned long long z[4] = {0, 0, 0, 0};
+    RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z));
+  }
+#endif
   return RT_OK;
 }
 

@@ -28,3 +28,4 @@ for i, nm in enumerate(names):
     print(f"  {nm:20s} {100.0 * a[8 + i] / max(tot, 1):6.2f} %")
 print(f"  (of intake: vmcnt wait) {100.0 * a[7] / max(tot, 1):6.2f} %")
 print(f"  {'other (setup/store)':20s} {100.0 * (tot - sum(a[8:14])) / max(tot, 1):6.2f} %")
+print(f"culling: {a[4] / max(a[5], 1):.2f} candidate spheres per lane and chunk, drain loop {a[6] / max(a[5], 1):.2f} turns per lane (= wave maximum)")
