@@ -32,6 +32,9 @@
 #ifndef RT_CULL
 #define RT_CULL 1         // shadow scan: per-lane cone culling of spheres (0 = every sphere for every lane)
 #endif
+#ifndef RT_CULL_STATS
+#define RT_CULL_STATS 0   // diagnostic build: candidate / drain-turn counts of the culled shadow scan (tools/stamps.py)
+#endif
 #ifndef RT_STAMPS
 #define RT_STAMPS 0       // diagnostic build: per-phase s_memtime sums into counters[.][8..15]
 #endif
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void rt_camera_table_kernel(const float4* __re
 // m_k >= 0).  L is a unit vector (a = 1 +- 2e-7): the residual of q = nb along L enters |l|^2 only
 // to second order.
 // ------------------------------------------------------------------------------------------
-#if RT_STAMPS
+#if RT_CULL_STATS
 static __device__ unsigned long long g_dbg[4];
 #define g_dbg_rel dbg_rel_
 #define g_dbg_lanes dbg_lanes_
@@ -351,7 +354,7 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          float mr, float mg, float mb, float spec, uint32_t level_key,
                                          float& lr, float& lg, float& lb) {
-#if RT_STAMPS
+#if RT_CULL_STATS
   unsigned dbg_rel_ = 0, dbg_lanes_ = 0, dbg_iters_ = 0;
 #endif
   const int nrays = 1 + L.ns;
@@ -474,11 +477,11 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
           no |= __float_as_uint(c);           // origin inside the sphere: never hit
           rel = __builtin_amdgcn_alignbit(rel, ~no, 31);   // rel = rel << 1 | (sign clear)
         }
-#if RT_STAMPS
+#if RT_CULL_STATS
         g_dbg_rel += __popc(rel); g_dbg_lanes += 1;
 #endif
         while (__ballot(rel != 0u) != 0ull) {
-#if RT_STAMPS
+#if RT_CULL_STATS
           g_dbg_iters += 1;
 #endif
           if (rel != 0u) {
@@ -536,7 +539,7 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
       } else { ad += wd; as += ws; }
     }
   }
-#if RT_STAMPS
+#if RT_CULL_STATS
   dbg_flush(dbg_rel_, dbg_lanes_, dbg_iters_);
 #endif
   if (!(spec > 0.0f)) { ps = 0.f; as = 0.f; }                        // :191 / :206
@@ -863,15 +866,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   };
   int hcur = gwave % kTileCounters;
   uint32_t dry = 0u;               // counters this wave has seen exhausted
-  int cl_left = 0;                 // slots of the current claim not yet started
-  int cl_frame = 0, cl_ty = 0, cl_tx = 0;   // tile of the claim's next slot
-  auto decode_claim = [&](int tile_id) {    // two scalar divisions per claim; then K tiles further per slot
-    cl_frame = tile_id / tiles_per_frame;
-    const int rem = tile_id - cl_frame * tiles_per_frame;
-    cl_ty = rem / p.tiles8_x;
-    cl_tx = rem - cl_ty * p.tiles8_x;
-  };
-  if (gwave < total_tiles) { cl_left = 1; decode_claim(gwave); }
+  // (tile records are self-describing and lie in tile-id order, frame after frame, so the supply side
+  // deals in tile ids only: no decoding into frame / row / column here)
+  int cl_left = 0, cl_id = 0;      // slots of the current claim not yet started, tile id of the next one
+  if (gwave < total_tiles) { cl_left = 1; cl_id = gwave; }
   bool endgame = false;            // the home counter is exhausted: claims are made one tile at a time
   int pf_n = 0, pf_c = 0;          // the claim being requested (lane 0 receives the counter value)
   int nx_n = 0, nx_id = 0;         // the claim after the current one: slots, first tile id
@@ -908,7 +906,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             bool stalled = false;              // the ring has room but the next claim has not landed
             while (tail - head < uint32_t(kRing) && !supply_done) {
               if (cl_left == 0) {
-                if (nx_n > 0) { cl_left = nx_n; nx_n = 0; decode_claim(nx_id); continue; }
+                if (nx_n > 0) { cl_left = nx_n; nx_n = 0; cl_id = nx_id; continue; }
                 if (!endgame) { stalled = true; break; }
                 // endgame: look (coherently) for a counter that still has tiles, claim one synchronously
                 int next = total_tiles;
@@ -923,23 +921,20 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
                 if (lane == 0) c2 = atomicAdd(p.chunk_counter + hcur * 32, 1);
                 c2 = __builtin_amdgcn_readfirstlane(c2);
                 const int id = (first_of(hcur) + c2) * kTileCounters + hcur;
-                if (id < total_tiles) { cl_left = 1; decode_claim(id); }
+                if (id < total_tiles) { cl_left = 1; cl_id = id; }
                 else dry |= 1u << hcur;
                 continue;
               }
-              if (cl_frame >= p.n_frames) { cl_left = 0; continue; }   // the rest of this claim lies beyond the end
+              if (cl_id >= total_tiles) { cl_left = 0; continue; }   // the rest of this claim lies beyond the end
               // ---- issue the tile: 36 lanes x 4 bytes (indices + header) straight into ring[slot]
               const uint32_t slot = tail & uint32_t(kRing - 1);
               if (lane < kVisTile / 2)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(
-                        p.vis + (size_t)cl_frame * p.vis_stride + ((size_t)cl_ty * p.tiles8_x + cl_tx) * kVisTile + lane * 2),
+                    (const __attribute__((address_space(1))) void*)(p.vis + (size_t)cl_id * kVisTile + lane * 2),
                     (__attribute__((address_space(3))) void*)(ring + slot * kVisTile), 4, 0, 0);
               ++tail;
               --cl_left;
-              cl_tx += kTileCounters;
-              while (cl_tx >= p.tiles8_x) { cl_tx -= p.tiles8_x; ++cl_ty; }
-              while (cl_ty >= p.tiles8_y) { cl_ty -= p.tiles8_y; ++cl_frame; }
+              cl_id += kTileCounters;
             }
             if (asked) {                       // read the claim back
               const int slot = first_of(hcur) + __builtin_amdgcn_readfirstlane(pf_c);
@@ -1647,7 +1642,7 @@ int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]) {
     for (int s = 0; s < kCounterSlots; ++s) out[k] += host[s * kCounterWords + k];
   }
   out[0] += ctx->host_primaries; out[2] += ctx->host_primaries;
-#if RT_STAMPS
+#if RT_CULL_STATS
   {  // culling statistics: [4] candidate spheres summed over lanes, [5] lane-chunks, [6] drain-loop turns summed over lanes
     unsigned long long h[4];
     RT_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h));
