@@ -13,8 +13,9 @@ total work per step is fixed => "strong" scaling.  Rays are counted by the kerne
 (rt_get_ray_counts), not modelled.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — FP32-VALU roofline of rt_stream_kernel from algorithmic flops and
-                 the kernel's live HIP-event duration on its launch stream;
+  roofline     — FP32-VALU roofline of the launch pair rt_visibility_kernel + rt_stream_kernel (one
+                 pair per batch and sample: primary rays / everything after them) from algorithmic
+                 flops (SURVEY.md §8d) and the pair's live HIP-event duration on its launch stream;
   cpu_baseline — the FP64 C++ restatement of the reference (oracle/, "port") timed on this
                  host's cores on a bounded number of whole frames of the same workload (rank 0, N = 1 only).
 """
@@ -215,10 +216,13 @@ def main():
             "mpixels_per_s": primary / dt / 1e6,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": f"rt_{args.kernel}_kernel", "kernel_ms": kern_ms,
+                         "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
+                                    "also cover the ~4 us rt_camera_table_kernel and a 4 KB memset)")
+                         if args.kernel == "stream" else "rt_pixel_kernel", "kernel_ms": kern_ms,
                          "flops_per_launch": fl,
-                         "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d; "
-                                 "HBM traffic is the framebuffer only (3 B/pixel)"},
+                         "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d, i.e. "
+                                 "the brute-force count: the kernels cull spheres per lane and execute fewer; "
+                                 "HBM traffic (PMC, profiles/) is the framebuffer + 2.25 B/pixel of hit indices"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)

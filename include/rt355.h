@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_MAX_SPHERES 2048      /* 32 B of LDS per sphere (geometry + camera table): 64 KiB   */
+#define RT_MAX_SPHERES 2048      /* 16 B of LDS per sphere in the shading kernels: 32 KiB      */
 #define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
 #define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
 
@@ -81,9 +81,10 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream, int use_own_stream);
 int rt_synchronize(rt_ctx* ctx);
 
 /* Tuning / diagnostic options (no reference counterpart).
- *   RT_OPT_KERNEL: RT_KERNEL_STREAM (default) = workgroup work-queue kernel that compacts hits into
- *   dense shading batches; RT_KERNEL_PIXEL = one thread per pixel, whole path in one loop (kept
- *   as the baseline for divergence counters).  Both compute the same arithmetic per ray. */
+ *   RT_OPT_KERNEL: RT_KERNEL_STREAM (default) = visibility pass (primary rays) followed by the
+ *   persistent-wave shading kernel that compacts hits into dense 64-lane passes; RT_KERNEL_PIXEL = one
+ *   thread per pixel, whole path in one loop (kept as the baseline for divergence counters).  Both
+ *   compute the same arithmetic per ray. */
 #define RT_OPT_KERNEL 1
 #define RT_KERNEL_STREAM 0
 #define RT_KERNEL_PIXEL 1
@@ -154,8 +155,9 @@ int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_by
 int rt_get_ray_counts(rt_ctx* ctx, uint64_t out[4]);
 int rt_reset_ray_counts(rt_ctx* ctx);
 
-/* Raw counter words summed over slots (diagnostics): [0..3] as rt_get_ray_counts' inputs, [8..15]
- * per-phase s_memtime sums of the stream kernel, non-zero only in a -DRT_STAMPS=1 build. */
+/* Raw counter words summed over slots (diagnostics): [0..3] as rt_get_ray_counts' inputs, [7..15]
+ * per-phase s_memtime sums of the stream kernel (tools/stamps.py), non-zero only in a -DRT_STAMPS=1
+ * build; [4..6] culling statistics in a -DRT_CULL_STATS=1 build. */
 int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]);
 
 /* Build/ABI information. */
