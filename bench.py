@@ -68,11 +68,11 @@ def cpu_baseline(wl, target_s=15.0):
     from raytracer_amd.scenes import pack_scene
     p = pack_scene(scene)
 
-    def run_frame(seed):
+    def run_frame(seed, nthreads=None):
         t0 = time.perf_counter()
         o = cpu_oracle.render_pixels(p.geom4[:, :3], p.radius, p.mat4[:, :3], p.spec, p.mat4[:, 3],
                                      p.lights, p.area_samples, w, h, max_depth=D, mode="K", seed=seed,
-                                     threads=threads)
+                                     threads=threads if nthreads is None else nthreads)
         dt = time.perf_counter() - t0
         rays = int(o["trace_levels"].sum()) + (1 + p.area_samples) * int(o["hit_levels"].sum())
         return rays, dt
@@ -83,8 +83,10 @@ def cpu_baseline(wl, target_s=15.0):
     while dt < target_s and frames < 1024:
         r_, d_ = run_frame(frames)
         rays += r_; dt += d_; frames += 1
+    r1, d1 = run_frame(0, 1)     # the same restatement on one thread, one frame
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
                 sample=f"{frames} whole frames of the workload ({rays} rays, {dt:.1f} s), FP64, OpenMP",
+                single_thread_mrays=r1 / d1 / 1e6,
                 python_reference_mrays_1core=PY_REFERENCE_MRAYS)
 
 

@@ -156,6 +156,27 @@ def test_full_frames_against_live_oracle(renderer, oracle, w, h, n, seed, D, ns,
         <= max(8, 2e-3 * o["trace_levels"].sum())
 
 
+def test_full_scale_multisample_and_noise_statistics(renderer, oracle):
+    """samples > 1 in keyed mode at BASELINE's full size (the reference's main()
+    renders at spp 2, raytracer.py:330).  Per-pixel parity of a 1080p spp-4 frame, and the noise itself:
+    mean and variance over 8 seeds agree with the oracle's (the jitter / area-light streams are the same
+    pure functions of position on both sides)."""
+    scene = generate_scene(8, 1, 1920, 1080, keep_default=True)
+    renderer.upload_scene(scene)
+    img, hit = renderer.render(1920, 1080, 4, max_depth=5, rng_mode="K", seed=21, return_hit_index=True)
+    o = oracle.render_scene(scene, 1920, 1080, samples=4, max_depth=5, mode="K", seed=21)
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+    w, h = 480, 270
+    gpu = np.stack([renderer.render_chunk(0, w, 0, h, w, h, 1, max_depth=5, rng_mode="K", seed=s).cpu().numpy()
+                    for s in range(8)]).astype(np.float64)
+    ref = np.stack([np.clip(oracle.render_scene(scene, w, h, samples=1, max_depth=5, mode="K", seed=s)["color"], 0, 1)
+                    for s in range(8)]).reshape(gpu.shape)
+    assert abs(gpu.mean() - ref.mean()) < 1e-5
+    vg, vr = gpu.var(axis=0).sum(), ref.var(axis=0).sum()
+    assert vr > 0 and abs(vg - vr) / vr < 0.02
+    assert np.abs(gpu.mean(axis=0) - ref.mean(axis=0)).max(-1).mean() < 1e-4
+
+
 # ---- hand-made edge scenes (same as tests/test_oracle_semantics.py) --------------------------
 def _mat(c=(1, 1, 1), spec=1.0, refl=0.0):
     return Material(Vector3(*c), specular=spec, reflection=refl)

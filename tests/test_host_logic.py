@@ -122,3 +122,23 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in src.replace("oracle/", "").lower() or f in ("__init__.py",) \
                     or "import oracle" not in src and "from oracle" not in src, f
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_presentation_helpers(tmp_path):
+    """the frame is what glTexImage2D / an image file takes."""
+    from raytracer_amd import present
+    img = (np.arange(5 * 7 * 3) % 256).astype(np.uint8).reshape(5, 7, 3)
+    w, h, raw = present.texture_bytes(img[:, ::1])
+    assert (w, h) == (7, 5) and raw == img.tobytes()
+    p = present.save_image(img, str(tmp_path / "f.ppm"))
+    data = open(p, "rb").read()
+    assert data.startswith(b"P6\n7 5\n255\n") and data.endswith(img.tobytes())
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    if Image is not None:
+        q = present.save_image(img, str(tmp_path / "f.png"))
+        assert np.array_equal(np.asarray(Image.open(q)), img)
+    with pytest.raises(ValueError):
+        present.as_host_rgb(img.astype(np.float32))
