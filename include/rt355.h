@@ -98,6 +98,14 @@ int rt_set_option(rt_ctx* ctx, int option, int value);
 int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const float* spec,
                     int n_spheres, const rt_lights* lights);
 
+/* Material.refraction / Material.refractive_index (raytracer.py:43, :213-230, :252-254) of the spheres
+ * of the uploaded scene, n_spheres values each (host pointers).  rt_upload_scene resets them to
+ * Material's defaults (0, 1); call this after it.  While any refraction is > 0 the renderer follows
+ * both children of a hit, a shadow ray is blocked only by an opaque NEAREST hit (:187, :202), pixels
+ * are summed with float atomics (run-to-run differences at FP32 rounding level), and
+ * RT_KERNEL_PIXEL is refused. */
+int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refractive_index, int n_spheres);
+
 /* render(width, height, samples) (raytracer.py:310-325): the whole frame.
  *   out_rgb: device uint8 [height][width][3], row 0 = top, tightly packed — the array the
  *            reference returns and hands to glTexImage2D (raytracer.py:346).

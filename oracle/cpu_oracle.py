@@ -28,6 +28,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         _lib.rto_render_pixels.restype = ctypes.c_int
+        _lib.rto_render_pixels2.restype = ctypes.c_int
         _lib.rto_max_threads.restype = ctypes.c_int
     return _lib
 
@@ -38,7 +39,7 @@ def _p(a, ct):
 
 def render_pixels(center, radius, color, specular, reflection, lights, area_samples, width, height,
                   pixels=None, samples=1, max_depth=5, mode="K", seed=0, camera=None,
-                  precision="f64", threads=0):
+                  precision="f64", threads=0, refraction=None, refractive_index=None):
     """Render the listed (x, y) pixels (or the full frame if ``pixels`` is None).
 
     Scene arrays are float32 (the values the kernel gets); the oracle widens them to double.
@@ -52,6 +53,10 @@ def render_pixels(center, radius, color, specular, reflection, lights, area_samp
     n = len(radius)
     assert center.shape == (n, 3) and color.shape == (n, 3) and len(specular) == n == len(reflection)
     assert lights.shape == (20,)
+    refraction = None if refraction is None else f32(refraction).ravel()
+    refractive_index = None if refractive_index is None else f32(refractive_index).ravel()
+    assert refraction is None or len(refraction) == n
+    assert refractive_index is None or len(refractive_index) == n
     cam = f32(DEFAULT_CAMERA if camera is None else camera).reshape(12)
     if pixels is None:
         px, npx = None, width * height
@@ -61,9 +66,10 @@ def render_pixels(center, radius, color, specular, reflection, lights, area_samp
     out = dict(color=np.zeros((npx, 3)), rgb8=np.zeros((npx, 3), np.uint8),
                hit=np.zeros(npx, np.int32), trace_levels=np.zeros(npx, np.int64),
                hit_levels=np.zeros(npx, np.int64), margin=np.zeros(npx))
-    rc = L.rto_render_pixels(
+    rc = L.rto_render_pixels2(
         ctypes.c_int(n), _p(center, ctypes.c_float), _p(radius, ctypes.c_float),
         _p(color, ctypes.c_float), _p(specular, ctypes.c_float), _p(reflection, ctypes.c_float),
+        _p(refraction, ctypes.c_float), _p(refractive_index, ctypes.c_float),
         _p(lights, ctypes.c_float), ctypes.c_int(int(area_samples)), _p(cam, ctypes.c_float),
         ctypes.c_int(width), ctypes.c_int(height), _p(px, ctypes.c_int32), ctypes.c_int64(npx),
         ctypes.c_int(samples), ctypes.c_int(max_depth), ctypes.c_int({"C": 0, "K": 1}[mode]),
@@ -84,7 +90,8 @@ def render_scene(scene: dict, width, height, **kw):
     if cam is not None and hasattr(cam, "as_array"):
         cam = cam.as_array()
     return render_pixels(p.geom4[:, :3], p.radius, p.mat4[:, :3], p.spec, p.mat4[:, 3], p.lights,
-                         p.area_samples, width, height, camera=cam, **kw)
+                         p.area_samples, width, height, camera=cam, refraction=p.refr[:, 0],
+                         refractive_index=p.refr[:, 1], **kw)
 
 
 def max_threads() -> int:

@@ -192,7 +192,9 @@ def to_ref_scene(ref, scene: dict) -> dict:
         "spheres": [ref.Sphere(v(s.center), f(s.radius),
                                ref.Material(v(s.material.color),
                                             specular=f(s.material.specular),
-                                            reflection=f(s.material.reflection)))
+                                            reflection=f(s.material.reflection),
+                                            refraction=f(getattr(s.material, "refraction", 0)),
+                                            refractive_index=f(getattr(s.material, "refractive_index", 1))))
                     for s in scene["spheres"]],
     }
 

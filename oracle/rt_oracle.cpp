@@ -44,7 +44,7 @@ template <typename T>
 struct SceneT {
   int n = 0;
   std::vector<V3<T>> center, color;
-  std::vector<T> radius, specular, reflection;
+  std::vector<T> radius, specular, reflection, refraction, refractive_index;
   V3<T> p_pos, p_col; T p_int;                       // scene['global_light'], :79
   V3<T> a_pos, a_u, a_v, a_col; T a_int; int a_samples;  // scene['area_light'], :80
   V3<T> cam_o, cam_r, cam_u, cam_f;
@@ -133,7 +133,7 @@ V3<T> compute_lighting(const SceneT<T>& s, V3<T> point, V3<T> normal, V3<T> view
   {
     V3<T> ldir = normalize(sub(s.p_pos, point));                          // :198
     V3<T> so = add(point, muls(normal, T(0.001)));                        // :199
-    if (!find_nearest(s, so, ldir, &sh, (double*)nullptr)) {              // :200-202 (refraction == 0)
+    if (!find_nearest(s, so, ldir, &sh, (double*)nullptr) || s.refraction[sh.idx] > 0) {   // :200-202
       T diffuse = max0(dot(normal, ldir));                                // :203
       color = add(color, muls(muls(mulv(s.color[mat], s.p_col), s.p_int), diffuse));  // :204
       if (spec_k > 0) {                                                   // :206
@@ -152,7 +152,7 @@ V3<T> compute_lighting(const SceneT<T>& s, V3<T> point, V3<T> normal, V3<T> view
       V3<T> lp = add(add(s.a_pos, muls(s.a_u, ru)), muls(s.a_v, rv));     // :182
       V3<T> ldir = normalize(sub(lp, point));                             // :183
       V3<T> so = add(point, muls(normal, T(0.001)));                      // :184
-      if (!find_nearest(s, so, ldir, &sh, (double*)nullptr)) {            // :185-187
+      if (!find_nearest(s, so, ldir, &sh, (double*)nullptr) || s.refraction[sh.idx] > 0) {   // :185-187
         T diffuse = max0(dot(normal, ldir));                              // :188
         contrib = add(contrib, muls(muls(s.a_col, s.a_int), diffuse));    // :189
         if (spec_k > 0) {                                                 // :191
@@ -167,8 +167,31 @@ V3<T> compute_lighting(const SceneT<T>& s, V3<T> point, V3<T> normal, V3<T> view
   return color;                                                           // :211
 }
 
+template <typename T>
+V3<T> trace_ray(const SceneT<T>& s, V3<T> o, V3<T> d, int level, int D, const Rng& rng, PixelStats* st);
+
+// compute_refraction, raytracer.py:213-230
+template <typename T>
+V3<T> compute_refraction(const SceneT<T>& s, V3<T> d, V3<T> hit_point, V3<T> normal, int mat, int level, int D,
+                         const Rng& rng, PixelStats* st) {
+  T n1 = T(1);                                                            // :214
+  T n2 = s.refractive_index[mat];                                         // :215
+  T cos_i = -dot(normal, d);                                              // :217
+  if (cos_i < 0) {                                                        // :218-221
+    cos_i = -cos_i;
+    normal = muls(normal, T(-1));
+    T tmp = n1; n1 = n2; n2 = tmp;
+  }
+  T n = n1 / n2;                                                          // :223
+  T k = T(1) - n * n * (T(1) - cos_i * cos_i);                            // :224
+  if (k < 0) return {0, 0, 0};                                            // :225-226 total internal reflection
+  V3<T> rd = normalize(add(muls(d, n), muls(normal, n * cos_i - std::sqrt(k))));   // :228
+  V3<T> ro = sub(hit_point, muls(normal, T(0.001)));                      // :229
+  return trace_ray(s, ro, rd, level + 1, D, rng, st);                     // :230
+}
+
 // trace_ray, raytracer.py:232-260, with the literal depth limit 5 (:233) made a parameter D:
-// `level > D` returns black.  Refraction (:252-254) is out of scope (always 0).
+// `level > D` returns black.
 template <typename T>
 V3<T> trace_ray(const SceneT<T>& s, V3<T> o, V3<T> d, int level, int D, const Rng& rng, PixelStats* st) {
   if (level > D) return {0, 0, 0};                                        // :233-234
@@ -185,6 +208,11 @@ V3<T> trace_ray(const SceneT<T>& s, V3<T> o, V3<T> d, int level, int D, const Rn
     V3<T> ro = add(h.point, muls(h.normal, T(0.001)));                    // :247
     V3<T> rc = trace_ray(s, ro, rd, level + 1, D, rng, st);               // :248
     color = add(muls(color, T(1) - refl), muls(rc, refl));                // :249
+  }
+  T refr = s.refraction[h.idx];
+  if (refr > 0) {                                                         // :252
+    V3<T> fc = compute_refraction(s, d, h.point, h.normal, h.idx, level, D, rng, st);   // :253
+    color = add(muls(color, T(1) - refr), muls(fc, refr));                // :254
   }
   st->hit_levels++;
   V3<T> light = compute_lighting(s, h.point, h.normal, muls(d, T(-1)), h.idx, rng,
@@ -212,10 +240,15 @@ V3<T> render_pixel(const SceneT<T>& s, int x, int y, int width, int height, int 
 
 template <typename T>
 void build_scene(SceneT<T>& s, int n, const float* center, const float* radius, const float* color,
-                 const float* specular, const float* reflection, const float* lights,
-                 int area_samples, const float* camera) {
+                 const float* specular, const float* reflection, const float* refraction,
+                 const float* refractive_index, const float* lights, int area_samples, const float* camera) {
   s.n = n;
   s.center.resize(n); s.color.resize(n); s.radius.resize(n); s.specular.resize(n); s.reflection.resize(n);
+  s.refraction.assign(n, T(0)); s.refractive_index.assign(n, T(1));   // Material defaults, :43
+  for (int i = 0; i < n; ++i) {
+    if (refraction) s.refraction[i] = T(refraction[i]);
+    if (refractive_index) s.refractive_index[i] = T(refractive_index[i]);
+  }
   for (int i = 0; i < n; ++i) {
     s.center[i] = {T(center[3 * i]), T(center[3 * i + 1]), T(center[3 * i + 2])};
     s.color[i] = {T(color[3 * i]), T(color[3 * i + 1]), T(color[3 * i + 2])};
@@ -230,12 +263,14 @@ void build_scene(SceneT<T>& s, int n, const float* center, const float* radius, 
 
 template <typename T>
 int run(int n, const float* center, const float* radius, const float* color, const float* specular,
-        const float* reflection, const float* lights, int area_samples, const float* camera,
+        const float* reflection, const float* refraction, const float* refractive_index,
+        const float* lights, int area_samples, const float* camera,
         int width, int height, const int32_t* pixels, int64_t n_pixels, int samples, int D, int mode,
         uint64_t seed, int threads, double* out_color, uint8_t* out_rgb8, int32_t* out_hit,
         int64_t* out_trace_levels, int64_t* out_hit_levels, double* out_margin) {
   SceneT<T> s;
-  build_scene(s, n, center, radius, color, specular, reflection, lights, area_samples, camera);
+  build_scene(s, n, center, radius, color, specular, reflection, refraction, refractive_index, lights,
+              area_samples, camera);
   uint32_t seed32 = uint32_t(seed ^ (seed >> 32));
   if (!pixels) n_pixels = int64_t(width) * height;
 #ifdef _OPENMP
@@ -267,6 +302,25 @@ extern "C" {
 
 // precision: 0 = double (the oracle), 1 = float (diagnostic).  pixels = NULL renders the full
 // frame row-major.  Outputs may be NULL.  `hit`/`margin` refer to the LAST sample's primary ray.
+// refraction / refractive_index: per sphere, or NULL for the Material defaults 0 / 1 (raytracer.py:43).
+int rto_render_pixels2(int n, const float* center, const float* radius, const float* color,
+                       const float* specular, const float* reflection, const float* refraction,
+                       const float* refractive_index, const float* lights,
+                       int area_samples, const float* camera, int width, int height,
+                       const int32_t* pixels, int64_t n_pixels, int samples, int max_depth, int mode,
+                       uint64_t seed, int precision, int threads, double* out_color,
+                       uint8_t* out_rgb8, int32_t* out_hit, int64_t* out_trace_levels,
+                       int64_t* out_hit_levels, double* out_margin) {
+  if (n < 0 || width <= 0 || height <= 0 || samples <= 0 || area_samples <= 0) return -1;
+  if (precision == 0)
+    return run<double>(n, center, radius, color, specular, reflection, refraction, refractive_index, lights,
+                       area_samples, camera, width, height, pixels, n_pixels, samples, max_depth, mode, seed,
+                       threads, out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
+  return run<float>(n, center, radius, color, specular, reflection, refraction, refractive_index, lights,
+                    area_samples, camera, width, height, pixels, n_pixels, samples, max_depth, mode, seed,
+                    threads, out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
+}
+
 int rto_render_pixels(int n, const float* center, const float* radius, const float* color,
                       const float* specular, const float* reflection, const float* lights,
                       int area_samples, const float* camera, int width, int height,
@@ -274,14 +328,10 @@ int rto_render_pixels(int n, const float* center, const float* radius, const flo
                       uint64_t seed, int precision, int threads, double* out_color,
                       uint8_t* out_rgb8, int32_t* out_hit, int64_t* out_trace_levels,
                       int64_t* out_hit_levels, double* out_margin) {
-  if (n < 0 || width <= 0 || height <= 0 || samples <= 0 || area_samples <= 0) return -1;
-  if (precision == 0)
-    return run<double>(n, center, radius, color, specular, reflection, lights, area_samples, camera,
-                       width, height, pixels, n_pixels, samples, max_depth, mode, seed, threads,
-                       out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
-  return run<float>(n, center, radius, color, specular, reflection, lights, area_samples, camera,
-                    width, height, pixels, n_pixels, samples, max_depth, mode, seed, threads,
-                    out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
+  return rto_render_pixels2(n, center, radius, color, specular, reflection, nullptr, nullptr, lights,
+                            area_samples, camera, width, height, pixels, n_pixels, samples, max_depth, mode,
+                            seed, precision, threads, out_color, out_rgb8, out_hit, out_trace_levels,
+                            out_hit_levels, out_margin);
 }
 
 int rto_max_threads(void) {

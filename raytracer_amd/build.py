@@ -23,7 +23,8 @@ SO = os.path.join(CSRC, "librt355.so")
 # wave-aggregated form that reads the result back (s_waitcnt vmcnt(0)) right after issuing it.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-gpu-sanitize", "-Wall", "-Wno-unused-function",
-               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+               "-munsafe-fp-atomics"]   # hardware float atomics for the refraction path's pixel sums
 
 
 def needs_build() -> bool:

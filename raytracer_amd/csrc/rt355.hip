@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/rt355.h"
 
@@ -80,6 +81,8 @@ struct RenderParams {
   const float4* geom;    // cx cy cz r^2
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
+  const float2* refr;    // refraction, refractive_index (raytracer.py:43); only read by the REFR kernels
+  int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
   int16_t* vis;            // [frame][tiles8_y][tiles8_x][kVisTile] per 8x8 tile: 64 primary hit indices (-1 = miss /
                            // outside the window) + header {tx | ty << 16, frame}; visibility pass -> stream kernel
@@ -347,9 +350,9 @@ static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigne
   atomicAdd(&g_dbg[0], (unsigned long long)r); atomicAdd(&g_dbg[1], (unsigned long long)l); atomicAdd(&g_dbg[2], (unsigned long long)i);
 }
 #endif
-template <int MODE, int B>
+template <int MODE, int B, bool REFR = false>
 __device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg,
-                                         const float4* __restrict__ gg, int n,
+                                         const float4* __restrict__ gg, const float2* __restrict__ refr, int n,
                                          float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          float mr, float mg, float mb, float spec, uint32_t level_key,
@@ -428,6 +431,21 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
         }
       }
     };
+    if constexpr (REFR) {
+      // Scenes with refractive materials: a shadow ray is blocked only if its NEAREST hit is opaque
+      // (raytracer.py:187, :202), so the any-hit shortcut does not apply: one full nearest-hit scan
+      // per ray, as the reference does.
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        if (base + k < nrays) {
+          float t;
+          int hi;
+          nearest_hit(sg, gg, n, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi);
+          const bool blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
+          m[k] = blocked ? 0.0f : -1.0f;
+        }
+      }
+    } else
 #if RT_CULL
     // Per-lane sphere culling.  The B rays of a lane leave one point towards one small light, so
     // almost every sphere is far from all of them; but lanes of a wave are unrelated pixels, so no
@@ -580,7 +598,7 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
   float lr, lg, lb;
-  lighting<MODE, kShadowBatch>(p.L, sg, p.geom, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+  lighting<MODE, kShadowBatch>(p.L, sg, p.geom, nullptr, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                m.x, m.y, m.z, spec, level_key, lr, lg, lb);
   load_state();
   const float refl = m.w;
@@ -729,7 +747,7 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
     primary_hit(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
                 cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     if (p.out_hit && last_sample) p.out_hit[frame_px + wpix] = idx;
-    if (idx < 0)   // :237-238 miss -> black (resolves the running mean over samples too)
+    if (idx < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
       finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &rgbx);
   }
   // tile-major hand-over: the 64 indices of this tile are 128 contiguous bytes; lanes outside the
@@ -739,7 +757,7 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
   rec[lane] = int16_t(idx);
   if (lane == 0)
     *reinterpret_cast<uint2*>(rec + 64) = make_uint2(uint32_t(col0 >> 3) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
-  if (p.out_rgb && last_sample) {
+  if (p.out_rgb && last_sample && !p.defer_output) {
     uint8_t* out = p.out_rgb + frame_px * 3;
     const bool aligned = cols == 8 && (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
     if (aligned) {
@@ -806,17 +824,21 @@ constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|fra
 #define RT_RING 4     // 4 keeps the kernel at 4 workgroups per CU up to 64 spheres (LDS); 8 and 16 measured no faster
 #endif
 constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
-constexpr int kWaveLdsBytes = kQueueFields * kBounceCap * 4 + kPendingCap * 8 + kRing * kVisTile * 2;
 constexpr int kTileCounters = 32;
 #ifndef RT_CLAIM
 #define RT_CLAIM 8
 #endif
 constexpr int kClaimMax = RT_CLAIM;
 
+constexpr int kBounceCapRefr = 192;                   // refraction: <= 63 queued + 2 x 64 pushed
+template <int CAP>
 struct Queue {
-  float* f;        // kQueueFields arrays of kBounceCap words (field-major: conflict-free lane access)
-  __device__ __forceinline__ float& at(int field, int i) const { return f[field * kBounceCap + i]; }
+  float* f;        // kQueueFields arrays of CAP words (field-major: conflict-free lane access)
+  __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
+constexpr int wave_lds_bytes(bool refr) {
+  return kQueueFields * (refr ? kBounceCapRefr : kBounceCap) * 4 + kPendingCap * 8 + kRing * kVisTile * 2;
+}
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
 // list reads and writes of different lanes across each other
@@ -829,8 +851,10 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // set b
   return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
 
-template <int MODE>
+template <int MODE, bool REFR>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams p) {
+  constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
+  constexpr int kWaveLdsBytes = wave_lds_bytes(REFR);
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);
   const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
@@ -838,8 +862,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_cams + kMaxBatch * 12);    // [kMaxBatch]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   unsigned char* mine = reinterpret_cast<unsigned char*>(s_seeds + kMaxBatch) + wave * kWaveLdsBytes;
-  Queue q{reinterpret_cast<float*>(mine)};
-  uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kBounceCap * 4);
+  Queue<kCap> q{reinterpret_cast<float*>(mine)};
+  uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kCap * 4);
   int16_t* ring = reinterpret_cast<int16_t*>(pend + kPendingCap);               // [kRing][kVisTile] tile records
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   if (tid < kMaxBatch * 12) s_cams[tid] = (&p.cams[0].origin[0])[tid];
@@ -1023,6 +1047,111 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         wpix = __float_as_uint(q.at(12, e));
         pixel_key = __float_as_uint(q.at(14, e));
       };
+      if constexpr (REFR) {
+        // ---- refraction in scope (raytracer.py:213-230, :252-254): a hit has up to two children.  With
+        //   C = ((m (1-r) + r C_refl) (1-f) + f C_refr) * l
+        // a node adds T m (1-r)(1-f) l to its PIXEL (float atomics into `accum`: the branches of a
+        // pixel end in different passes), and hands T r (1-f) l to the reflected, T f l to the
+        // refracted ray.  Records carry no acc here; pixels are resolved by rt_resolve_kernel.
+        bool push_r = false, push_f = false;
+        float rpx = 0.f, rpy = 0.f, rpz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rtr = 0.f, rtg = 0.f, rtb = 0.f;
+        float fpx = 0.f, fpy = 0.f, fpz = 0.f, fdx = 0.f, fdy = 0.f, fdz = 0.f, ftr = 0.f, ftg = 0.f, ftb = 0.f;
+        uint32_t meta_r = 0u, meta_f = 0u;
+        if (have) {
+          const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
+          ++n_shade;
+          const float4 s = sg[idx];
+          const float4 m = p.mat[idx];
+          const float spec = p.spec[idx];
+          const float2 rf = p.refr[idx];
+          float nx = px - s.x, ny = py - s.y, nz = pz - s.z;               // :139-140
+          {
+            const float inv = frsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+            nx *= inv; ny *= inv; nz *= inv;
+          }
+          const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
+          float lr, lg, lb;
+          lighting<MODE, 1, true>(p.L, sg, p.geom, p.refr, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz,
+                                  sx, sy, sz, m.x, m.y, m.z, spec, mix(pixel_key, uint32_t(level + 1)), lr, lg, lb);
+          late_state();
+          s2 = RT_NOW();
+          const float refl = m.w, refr = rf.x;
+          const float own = (1.0f - refl) * (1.0f - refr);                   // :249, :254 (1 - 0 = 1 exactly)
+          float* a = p.accum + ((long long)rframe * p.accum_stride_px + wpix) * 3;
+          unsafeAtomicAdd(a + 0, tr * (m.x * own) * lr);
+          unsafeAtomicAdd(a + 1, tg * (m.y * own) * lg);
+          unsafeAtomicAdd(a + 2, tb * (m.z * own) * lb);
+          const bool deeper = level < p.max_depth;                           // :233 `depth > D` -> black
+          if (refl > 0.0f && deeper) {                                       // :245-248
+            const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));
+            rdx = fmaf(-dn2, nx, dx); rdy = fmaf(-dn2, ny, dy); rdz = fmaf(-dn2, nz, dz);
+            float t;
+            int idx2;
+            ++n_trace;
+            nearest_hit(sg, p.geom, p.n_spheres, sx, sy, sz, rdx, rdy, rdz, t, idx2);
+            if (idx2 >= 0) {
+              push_r = true;
+              rpx = fmaf(rdx, t, sx); rpy = fmaf(rdy, t, sy); rpz = fmaf(rdz, t, sz);
+              const float k = refl * (1.0f - refr);
+              rtr = tr * k * lr; rtg = tg * k * lg; rtb = tb * k * lb;
+              meta_r = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
+            }
+          }
+          if (refr > 0.0f && deeper) {                                       // :252-253 -> compute_refraction
+            float n1 = 1.0f, n2 = rf.y;                                      // :214-215
+            float cos_i = -fmaf(nz, dz, fmaf(ny, dy, nx * dx));              // :217
+            float qx = nx, qy = ny, qz = nz;
+            if (cos_i < 0.0f) {                                              // :218-221
+              cos_i = -cos_i; qx = -qx; qy = -qy; qz = -qz;
+              const float tmp = n1; n1 = n2; n2 = tmp;
+            }
+            const float n = n1 / n2;                                         // :223
+            const float k = 1.0f - n * n * (1.0f - cos_i * cos_i);           // :224
+            if (k >= 0.0f) {                                                 // :225 (else total internal reflection: black)
+              const float w = n * cos_i - fsqrt(k);
+              fdx = fmaf(qx, w, dx * n); fdy = fmaf(qy, w, dy * n); fdz = fmaf(qz, w, dz * n);   // :228
+              const float inv = frsq(fmaf(fdz, fdz, fmaf(fdy, fdy, fdx * fdx)));
+              fdx *= inv; fdy *= inv; fdz *= inv;
+              const float ox = fmaf(qx, -0.001f, px), oy = fmaf(qy, -0.001f, py), oz = fmaf(qz, -0.001f, pz);  // :229
+              float t;
+              int idx2;
+              ++n_trace;
+              nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, fdx, fdy, fdz, t, idx2);
+              if (idx2 >= 0) {
+                push_f = true;
+                fpx = fmaf(fdx, t, ox); fpy = fmaf(fdy, t, oy); fpz = fmaf(fdz, t, oz);
+                ftr = tr * refr * lr; ftg = tg * refr * lg; ftb = tb * refr * lb;
+                meta_f = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
+              }
+            }
+          }
+        }
+        wave_lds_fence();   // every lane has its whole record in registers before slots are rewritten
+        const unsigned long long mask_r = __ballot(push_r), mask_f = __ballot(push_f);
+        if (push_r) {
+          const int slot = base + lanes_below(mask_r);
+          q.at(0, slot) = rpx; q.at(1, slot) = rpy; q.at(2, slot) = rpz;
+          q.at(3, slot) = rdx; q.at(4, slot) = rdy; q.at(5, slot) = rdz;
+          q.at(6, slot) = rtr; q.at(7, slot) = rtg; q.at(8, slot) = rtb;
+          q.at(12, slot) = __uint_as_float(wpix);
+          q.at(13, slot) = __uint_as_float(meta_r);
+          q.at(14, slot) = __uint_as_float(pixel_key);
+        }
+        if (push_f) {
+          const int slot = base + __popcll(mask_r) + lanes_below(mask_f);
+          q.at(0, slot) = fpx; q.at(1, slot) = fpy; q.at(2, slot) = fpz;
+          q.at(3, slot) = fdx; q.at(4, slot) = fdy; q.at(5, slot) = fdz;
+          q.at(6, slot) = ftr; q.at(7, slot) = ftg; q.at(8, slot) = ftb;
+          q.at(12, slot) = __uint_as_float(wpix);
+          q.at(13, slot) = __uint_as_float(meta_f);
+          q.at(14, slot) = __uint_as_float(pixel_key);
+        }
+        n_bounce = base + __popcll(mask_r) + __popcll(mask_f);
+        wave_lds_fence();
+        const unsigned long long s3 = RT_NOW();
+        st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
+        continue;
+      }
       if (have) {
         const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
         ++n_shade;
@@ -1185,6 +1314,27 @@ thread_local std::string g_last_error;
 
 }  // namespace
 
+// REFR path: every pixel of the window from its sum over samples and tree nodes in `accum`
+// (render_pixel :297, render :318, :325).
+__global__ __launch_bounds__(256) void rt_resolve_kernel(const RenderParams p) {
+  const long long win_px = (long long)p.nx * p.n_rows;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int frame = blockIdx.y;
+  if (i >= win_px) return;
+  const float* a = p.accum + ((long long)frame * p.accum_stride_px + i) * 3;
+  const float r = a[0] * p.inv_samples, g = a[1] * p.inv_samples, b = a[2] * p.inv_samples;
+  const long long gpix = (long long)frame * p.frame_stride_px + i;
+  if (p.out_f32) {
+    float* o = p.out_f32 + gpix * 3;
+    o[0] = fminf(1.0f, fmaxf(0.0f, r)); o[1] = fminf(1.0f, fmaxf(0.0f, g)); o[2] = fminf(1.0f, fmaxf(0.0f, b));
+  }
+  if (p.out_rgb) {
+    const uint32_t rgbx = pack_rgbx(r, g, b);
+    uint8_t* o = p.out_rgb + gpix * 3;
+    o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: context + C ABI
 // ------------------------------------------------------------------------------------------
@@ -1195,6 +1345,8 @@ struct rt_ctx {
   float4* d_geom = nullptr;
   float4* d_mat = nullptr;
   float* d_spec = nullptr;
+  float2* d_refr = nullptr;      // refraction, refractive_index per sphere (rt_set_refraction)
+  bool has_refr = false;         // some sphere has refraction > 0: the REFR kernels run
   unsigned long long* d_counters = nullptr;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
@@ -1230,8 +1382,8 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres) {
-  return geom_lds(n_spheres) + size_t(kMaxBatch) * 13 * 4 + size_t(kWaveLdsBytes) * (kBlock / 64);
+size_t stream_lds(int n_spheres, bool refr = false) {
+  return geom_lds(n_spheres) + size_t(kMaxBatch) * 13 * 4 + size_t(wave_lds_bytes(refr)) * (kBlock / 64);
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -1279,7 +1431,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   RT_HIP(ctx, hipSetDevice(ctx->device));
   const int batch = std::min(n_frames, kMaxBatch);
-  if (samples > 1) {  // running sums over samples, one slab per frame of a batch
+  const bool refr = ctx->has_refr;
+  if (refr && ctx->kernel != RT_KERNEL_STREAM)
+    return fail(ctx, RT_ESTATE, "refractive materials need the default kernel (RT_KERNEL_STREAM)");
+  if (samples > 1 || refr) {  // running sums over samples (and tree nodes), one slab per frame of a batch
     const size_t need = size_t(win_px) * 3 * size_t(batch);
     if (need > ctx->accum_floats) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1312,7 +1467,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.inv_aspect = float(height) / float(width);
   p.inv_samples = 1.0f / float(samples);
   p.n_spheres = ctx->n_spheres;
-  p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec;
+  p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
+  p.defer_output = refr ? 1 : 0;
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
   p.vis = ctx->d_vis;
@@ -1329,7 +1485,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   } else {
     per_frame = unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH);
   }
-  const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres) : pixel_lds(ctx->n_spheres);
+  const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres, refr) : pixel_lds(ctx->n_spheres);
 
   for (int f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
     const int nf = std::min(kMaxBatch, n_frames - f0);
@@ -1352,6 +1508,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         RT_HIP(ctx, hipGetLastError());
       }
     }
+    if (refr)   // every node of every sample adds into the pixel sums
+      RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));
     for (int s = 0; s < samples; ++s) {
       p.sample_index = s;
       if (stream_kernel) {
@@ -1360,16 +1518,23 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         const size_t vlds = 0;
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
-        const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus * RT_WAVES_PER_SIMD)), 1, 1);
+        // (and never more than the LDS lets stay resident)
+        const unsigned per_cu = unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
+        const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, kTileCounters * 128, ctx->stream));
         if (rng_mode == RT_RNG_KEYED) {
           hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_KEYED>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
-          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_KEYED>, sgrid, dim3(kBlock), lds, ctx->stream, p);
+          if (refr) hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_KEYED, true>), sgrid, dim3(kBlock), lds, ctx->stream, p);
+          else hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_KEYED, false>), sgrid, dim3(kBlock), lds, ctx->stream, p);
         } else {
           hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_CONSTANT>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
-          hipLaunchKernelGGL(rt_stream_kernel<RT_RNG_CONSTANT>, sgrid, dim3(kBlock), lds, ctx->stream, p);
+          if (refr) hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_CONSTANT, true>), sgrid, dim3(kBlock), lds, ctx->stream, p);
+          else hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_CONSTANT, false>), sgrid, dim3(kBlock), lds, ctx->stream, p);
         }
+        if (refr && s + 1 == samples)
+          hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
+                             ctx->stream, p);
       } else {
         if (rng_mode == RT_RNG_KEYED)
           hipLaunchKernelGGL(rt_pixel_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
@@ -1426,6 +1591,7 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_geom, sizeof(float4) * (RT_MAX_SPHERES + 8))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_mat, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_refr, sizeof(float2) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_chunk, kTileCounters * 128)) != hipSuccess) return bail(e, "hipMalloc");
@@ -1434,9 +1600,11 @@ int rt_create(int device_id, rt_ctx** out) {
     return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMemset");
-  const size_t big = stream_lds(RT_MAX_SPHERES);
-  if ((e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
-      (e = allow_big_lds(rt_stream_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess ||
+  const size_t big = stream_lds(RT_MAX_SPHERES), bigr = stream_lds(RT_MAX_SPHERES, true);
+  if ((e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED, false>, big)) != hipSuccess ||
+      (e = allow_big_lds(rt_stream_kernel<RT_RNG_CONSTANT, false>, big)) != hipSuccess ||
+      (e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED, true>, bigr)) != hipSuccess ||
+      (e = allow_big_lds(rt_stream_kernel<RT_RNG_CONSTANT, true>, bigr)) != hipSuccess ||
       (e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
       (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
@@ -1451,6 +1619,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_geom) (void)hipFree(ctx->d_geom);
   if (ctx->d_mat) (void)hipFree(ctx->d_mat);
   if (ctx->d_spec) (void)hipFree(ctx->d_spec);
+  if (ctx->d_refr) (void)hipFree(ctx->d_refr);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -1520,6 +1689,31 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
                    std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
   ctx->n_spheres = n_spheres;
+  ctx->has_refr = false;   // Material's defaults (raytracer.py:43) until rt_set_refraction says otherwise
+  return RT_OK;
+}
+
+int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refractive_index, int n_spheres) {
+  if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
+  if (ctx->n_spheres < 0) return fail(ctx, RT_ESTATE, "rt_upload_scene has not been called");
+  if (n_spheres != ctx->n_spheres)
+    return fail(ctx, RT_EINVAL, "n_spheres %d does not match the uploaded scene (%d)", n_spheres, ctx->n_spheres);
+  if (n_spheres > 0 && (!refraction || !refractive_index)) return fail(ctx, RT_EINVAL, "NULL array");
+  std::vector<float2> h(size_t(std::max(n_spheres, 1)));
+  bool any = false;
+  for (int i = 0; i < n_spheres; ++i) {
+    if (!std::isfinite(refraction[i]) || !std::isfinite(refractive_index[i]))
+      return fail(ctx, RT_EINVAL, "sphere %d: non-finite refraction value", i);
+    if (refraction[i] > 0.0f && !(refractive_index[i] > 0.0f))
+      return fail(ctx, RT_EINVAL, "sphere %d: refractive_index must be > 0", i);
+    h[size_t(i)] = make_float2(refraction[i], refractive_index[i]);
+    any = any || refraction[i] > 0.0f;
+  }
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_spheres > 0)
+    RT_HIP(ctx, hipMemcpy(ctx->d_refr, h.data(), sizeof(float2) * size_t(n_spheres), hipMemcpyHostToDevice));
+  ctx->has_refr = any;
   return RT_OK;
 }
 

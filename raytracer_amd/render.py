@@ -76,6 +76,10 @@ class Renderer:
         g, m, s = (np.ascontiguousarray(a, np.float32) for a in (p.geom4, p.mat4, p.spec))
         self._check(self._L.rt_upload_scene(self._h, g.ctypes.data, m.ctypes.data, s.ctypes.data,
                                             p.n_spheres, ctypes.byref(lights)))
+        if p.has_refraction:      # Material.refraction / .refractive_index (raytracer.py:43, :213-230)
+            f = np.ascontiguousarray(p.refr[:, 0], np.float32)
+            ri = np.ascontiguousarray(p.refr[:, 1], np.float32)
+            self._check(self._L.rt_set_refraction(self._h, f.ctypes.data, ri.ctypes.data, p.n_spheres))
         self._packed = p
         return p
 

@@ -47,8 +47,7 @@ class Vector3:
 
 @dataclass
 class Material:
-    """raytracer.py:42-48. ``refraction``/``refractive_index`` are carried but must be 0/unused:
-    the refraction branch (raytracer.py:213-230, 252-254) is out of scope."""
+    """raytracer.py:42-48 (refraction: raytracer.py:213-230, 252-254)."""
     color: Vector3
     specular: float = 0
     reflection: float = 0
@@ -150,7 +149,16 @@ class PackedScene:
     radius: np.ndarray       # [N]   float32 (kept for round-tripping to objects)
     lights: np.ndarray       # [20]  float32: ppos3 pcol3 pint | apos3 au3 av3 acol3 aint
     area_samples: int
+    refr: np.ndarray = None  # [N,2] float32: refraction, refractive_index (Material defaults 0, 1)
     _ct: RtLights = field(default=None, repr=False)
+
+    def __post_init__(self):
+        if self.refr is None:
+            self.refr = np.tile(np.array([0, 1], np.float32), (self.geom4.shape[0], 1))
+
+    @property
+    def has_refraction(self) -> bool:
+        return bool(np.any(self.refr[:, 0] > 0))
 
     @property
     def n_spheres(self) -> int:
@@ -176,8 +184,8 @@ def pack_scene(scene: dict) -> PackedScene:
     Values are rounded to float32 here, once; ``r*r`` is formed in float32 from the float32
     radius so the kernel sees exactly what :func:`scene_from_arrays` hands the FP64 oracle.
     Errors mirror what the reference would hit: a missing key raises ``KeyError``
-    (raytracer.py:156,176); non-sphere objects and refractive materials are rejected because
-    the cube / refraction branches are out of scope.
+    (raytracer.py:156,176); non-sphere objects are rejected because the cube branch is out of
+    scope.
     """
     spheres = scene["spheres"]
     n = len(spheres)
@@ -187,12 +195,14 @@ def pack_scene(scene: dict) -> PackedScene:
     mat = np.zeros((n, 4), np.float32)
     spec = np.zeros((n,), np.float32)
     rad = np.zeros((n,), np.float32)
+    refr = np.zeros((n, 2), np.float32)
     for i, s in enumerate(spheres):
         if not (hasattr(s, "center") and hasattr(s, "radius")):
             raise TypeError(f"scene['spheres'][{i}] is not a sphere (cubes are out of scope)")
         m = s.material
-        if float(getattr(m, "refraction", 0)) > 0:
-            raise NotImplementedError("material.refraction > 0 is out of scope for the HIP path")
+        refr[i] = (float(getattr(m, "refraction", 0)), float(getattr(m, "refractive_index", 1)))
+        if refr[i, 0] > 0 and not refr[i, 1] > 0:
+            raise ValueError(f"scene['spheres'][{i}]: refractive_index must be > 0")
         r32 = np.float32(s.radius)
         geom[i, :3] = _v3(s.center)
         geom[i, 3] = r32 * r32
@@ -207,23 +217,27 @@ def pack_scene(scene: dict) -> PackedScene:
     lights = np.array([*_v3(pl.position), *_v3(pl.color), float(pl.intensity),
                        *_v3(al.position), *_v3(al.u), *_v3(al.v), *_v3(al.color),
                        float(al.intensity)], dtype=np.float32)
-    for name, a in (("geom4", geom), ("mat4", mat), ("spec", spec), ("lights", lights)):
+    for name, a in (("geom4", geom), ("mat4", mat), ("spec", spec), ("lights", lights), ("refr", refr)):
         if not np.all(np.isfinite(a)):
             raise ValueError(f"scene has non-finite values in {name}")
-    return PackedScene(geom, mat, spec, rad, lights, ns)
+    return PackedScene(geom, mat, spec, rad, lights, ns, refr)
 
 
 def scene_from_arrays(center, radius, color, specular, reflection, lights=None,
-                      area_samples=12) -> dict:
+                      area_samples=12, refraction=None, refractive_index=None) -> dict:
     """Build a reference-style scene dict from arrays (float32 values widened to Python floats),
     so oracle and kernel see bit-identical inputs."""
     center = np.asarray(center, np.float32); radius = np.asarray(radius, np.float32)
     color = np.asarray(color, np.float32)
     specular = np.asarray(specular, np.float32); reflection = np.asarray(reflection, np.float32)
+    n = len(radius)
+    refraction = np.zeros(n, np.float32) if refraction is None else np.asarray(refraction, np.float32)
+    refractive_index = np.ones(n, np.float32) if refractive_index is None else np.asarray(refractive_index, np.float32)
     sph = [Sphere(Vector3(*map(float, center[i])), float(radius[i]),
                   Material(Vector3(*map(float, color[i])), specular=float(specular[i]),
-                           reflection=float(reflection[i])))
-           for i in range(len(radius))]
+                           reflection=float(reflection[i]), refraction=float(refraction[i]),
+                           refractive_index=float(refractive_index[i])))
+           for i in range(n)]
     d = default_scene()
     if lights is not None:
         v = [float(x) for x in np.asarray(lights, np.float32)]
@@ -294,3 +308,21 @@ def orbit_camera(frame: int, n_frames: int = 256, radius: float = 6.0,
     u = np.cross(r, f)
     return Camera(tuple(np.float32(o).tolist()), tuple(np.float32(r).tolist()),
                   tuple(np.float32(u).tolist()), tuple(np.float32(f).tolist()))
+
+
+def refractive_scene() -> dict:
+    """The reference's default scene with glass added (the reference itself only
+    ships refraction in a commented-out cube, raytracer.py:88-89): the front sphere becomes partly
+    refractive, and two glass spheres stand between the camera / the lights and the others, so that
+    refracted paths, total internal reflection candidates and the "shadow ray's nearest hit is
+    refractive" rule (raytracer.py:187, :202) are all exercised."""
+    s = default_scene()
+    m = s["spheres"][0].material
+    m.refraction, m.refractive_index = 0.6, 1.5
+    s["spheres"].append(Sphere(Vector3(-0.9, 0.6, -3.2), 0.45,
+                               Material(Vector3(0.9, 0.95, 1.0), specular=0.8, reflection=0.1,
+                                        refraction=0.85, refractive_index=1.33)))
+    s["spheres"].append(Sphere(Vector3(1.6, 1.4, -3.5), 0.6,
+                               Material(Vector3(1.0, 0.9, 0.8), specular=0.5, reflection=0.0,
+                                        refraction=0.7, refractive_index=0.8)))
+    return s

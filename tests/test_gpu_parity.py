@@ -12,7 +12,7 @@ import pytest
 
 from conftest import golden_scene_arrays, load_golden, scene_dict_from_arrays
 from raytracer_amd.scenes import (Camera, Material, Sphere, Vector3, default_scene,
-                                  generate_scene, orbit_camera, pack_scene)
+                                  generate_scene, orbit_camera, pack_scene, refractive_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -175,6 +175,59 @@ def test_full_scale_multisample_and_noise_statistics(renderer, oracle):
     vg, vr = gpu.var(axis=0).sum(), ref.var(axis=0).sum()
     assert vr > 0 and abs(vg - vr) / vr < 0.02
     assert np.abs(gpu.mean(axis=0) - ref.mean(axis=0)).max(-1).mean() < 1e-4
+
+
+@pytest.mark.parametrize("w,h,D,spp,mode", [(320, 240, 5, 1, "K"), (333, 187, 5, 2, "K"), (160, 120, 2, 1, "C"),
+                                            (640, 480, 8, 1, "K")])
+def test_refraction_against_oracle(renderer, oracle, w, h, D, spp, mode):
+    """compute_refraction (raytracer.py:213-230, :252-254) — both children of a
+    hit are followed — and the shadow rule "blocked only by an opaque nearest hit" (:187, :202)."""
+    scene = refractive_scene()
+    renderer.upload_scene(scene)
+    renderer.reset_ray_counts()
+    img, hit = renderer.render(w, h, spp, max_depth=D, rng_mode=mode, seed=4, return_hit_index=True)
+    o = oracle.render_scene(scene, w, h, samples=spp, max_depth=D, mode=mode, seed=4)
+    check_hits(hit.cpu().numpy(), o["hit"], o["margin"])
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+    rc = renderer.ray_counts()
+    assert rc["primary"] == w * h * spp and rc["shadow"] == 13 * rc["shaded_hits"]
+    assert abs(rc["shaded_hits"] - int(o["hit_levels"].sum())) <= max(8, 2e-3 * o["hit_levels"].sum())
+    assert abs(rc["primary"] + rc["reflection"] - int(o["trace_levels"].sum())) \
+        <= max(8, 2e-3 * o["trace_levels"].sum())
+    # unquantised colour, tiles and a later opaque scene on the same context
+    x1, y1 = min(200, w), min(110, h)
+    c = renderer.render_chunk(10, x1, 20, y1, w, h, spp, max_depth=D, rng_mode=mode, seed=4).cpu().numpy()
+    ref = np.clip(o["color"].reshape(h, w, 3)[20:y1, 10:x1], 0, 1)
+    assert (np.abs(c - ref).max(-1) < 1e-3).mean() >= PIXEL_FRACTION
+    rows = renderer.render_rows(w, h, spp, tile_rows=8, tile_first=1, tile_stride=3, max_depth=D, rng_mode=mode, seed=4)
+    from raytracer_amd import tiling
+    sel = tiling.local_rows(h, 8, 1, 3)
+    assert np.abs(rows.cpu().numpy().astype(int) - img.cpu().numpy()[sel].astype(int)).max() <= 1
+    renderer.upload_scene(default_scene())
+    img2 = renderer.render(w, h, 1, max_depth=D, rng_mode=mode, seed=4)
+    o2 = oracle.render_scene(default_scene(), w, h, samples=1, max_depth=D, mode=mode, seed=4)
+    check_rgb(img2.cpu().numpy(), o2["rgb8"])
+
+
+def test_refraction_glass_in_front_of_light_does_not_shadow(renderer, oracle):
+    """An opaque floor-like sphere lit through a glass sphere: the glass must not cast a shadow, an
+    opaque sphere at the same place must (raytracer.py:187, :202)."""
+    def scene(refraction):
+        s = default_scene()
+        s["spheres"] = [Sphere(Vector3(0, -101, -6), 100, _mat((0.8, 0.8, 0.8), spec=0.2)),
+                        Sphere(Vector3(1.2, 1.2, -3.0), 0.8,
+                               Material(Vector3(1, 1, 1), specular=0.5, reflection=0.0, refraction=refraction,
+                                        refractive_index=1.5))]
+        return s
+    imgs = []
+    for f in (0.9, 0.0):
+        sc = scene(f)
+        renderer.upload_scene(sc)
+        img = renderer.render(200, 150, 1, max_depth=5, rng_mode="C", seed=0).cpu().numpy()
+        o = oracle.render_scene(sc, 200, 150, max_depth=5, mode="C", seed=0)
+        check_rgb(img, o["rgb8"])
+        imgs.append(img.astype(int))
+    assert (imgs[0].sum(-1) > imgs[1].sum(-1) + 30).mean() > 0.01   # the opaque sphere's shadow is gone
 
 
 # ---- hand-made edge scenes (same as tests/test_oracle_semantics.py) --------------------------

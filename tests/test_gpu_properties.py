@@ -140,6 +140,34 @@ def test_abi_error_paths():
         L.rt_destroy(h)
 
 
+def test_refraction_abi(renderer):
+    """rt_set_refraction: argument checks, reset by rt_upload_scene, RT_KERNEL_PIXEL refused."""
+    L = _lib.load()
+    from raytracer_amd.scenes import refractive_scene
+    pk = renderer.upload_scene(refractive_scene())
+    n = pk.n_spheres
+    f = np.ascontiguousarray(pk.refr[:, 0]); ri = np.ascontiguousarray(pk.refr[:, 1])
+    assert L.rt_set_refraction(renderer._h, f.ctypes.data, ri.ctypes.data, n + 1) == -1
+    assert L.rt_set_refraction(renderer._h, None, ri.ctypes.data, n) == -1
+    bad = ri.copy(); bad[0] = 0.0
+    assert L.rt_set_refraction(renderer._h, f.ctypes.data, bad.ctypes.data, n) == -1
+    assert b"refractive_index" in L.rt_last_error(renderer._h)
+    renderer.set_kernel("pixel")
+    try:
+        with pytest.raises(_lib.RtError):
+            renderer.render(64, 48, 1)
+    finally:
+        renderer.set_kernel("stream")
+    a = renderer.render(64, 48, 1, rng_mode="C").cpu().numpy()
+    renderer.upload_scene(default_scene())          # resets refraction to Material's defaults
+    renderer.set_kernel("pixel")
+    try:
+        b = renderer.render(64, 48, 1, rng_mode="C").cpu().numpy()
+    finally:
+        renderer.set_kernel("stream")
+    assert not np.array_equal(a, b)
+
+
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
     pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""

@@ -85,7 +85,11 @@ def test_area_sample_count_matters_only_through_mean(oracle):
 def test_pack_scene_rejects_out_of_scope():
     s = default_scene()
     s["spheres"][0].material.refraction = 0.5
-    with pytest.raises(NotImplementedError):
+    s["spheres"][0].material.refractive_index = 1.5
+    pk = pack_scene(s)                      # refraction is in scope
+    assert pk.has_refraction and pk.refr[0].tolist() == [0.5, 1.5] and pk.refr[1].tolist() == [0.0, 1.0]
+    s["spheres"][0].material.refractive_index = 0.0
+    with pytest.raises(ValueError):
         pack_scene(s)
     s = default_scene()
     s["spheres"].append(object())
