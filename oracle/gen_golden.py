@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import cpu_oracle, ref_harness  # noqa: E402
-from raytracer_amd.scenes import (Camera, default_scene, generate_scene, orbit_camera,  # noqa: E402
+from raytracer_amd.scenes import (refractive_scene, Camera, default_scene, generate_scene, orbit_camera,  # noqa: E402
                                  pack_scene)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -42,14 +42,17 @@ def _worker(job):
 def _scene_from_kw(kw):
     from raytracer_amd.scenes import scene_from_arrays
     return scene_from_arrays(kw["center"], kw["radius"], kw["color"], kw["specular"],
-                             kw["reflection"], kw["lights"], kw["area_samples"])
+                             kw["reflection"], kw["lights"], kw["area_samples"],
+                             refraction=kw.get("refraction"), refractive_index=kw.get("refractive_index"))
 
 
 def scene_kw(scene):
     p = pack_scene(scene)
     return dict(center=p.geom4[:, :3].copy(), radius=p.radius.copy(), color=p.mat4[:, :3].copy(),
                 specular=p.spec.copy(), reflection=p.mat4[:, 3].copy(), lights=p.lights.copy(),
-                area_samples=p.area_samples)
+                area_samples=p.area_samples,
+                **(dict(refraction=p.refr[:, 0].copy(), refractive_index=p.refr[:, 1].copy())
+                   if p.has_refraction else {}))
 
 
 def run_reference(pool, skw, width, height, pixels, samples, D, mode, seed, cam=None, chunks=64):
@@ -164,6 +167,19 @@ def main():
             meta = dict(width=160, height=120, samples=2, max_depth=D, mode="K", seed=7,
                         scene="default scene rounded to float32")
             save(name, meta, skw, compact_full(res, 160, 120))
+
+    # --- refraction: glass added to the default scene, full small frames ----
+    for mode, D, spp in (("K", 5, 2), ("C", 3, 1)):
+        name = f"refr_glass_200x150_D{D}_spp{spp}_mode{mode}"
+        if want(name):
+            t0 = time.time()
+            skw = scene_kw(refractive_scene())
+            px = full_frame_pixels(200, 150)
+            res = run_reference(pool, skw, 200, 150, px, spp, D, mode, 3)
+            meta = dict(width=200, height=150, samples=spp, max_depth=D, mode=mode, seed=3,
+                        scene="raytracer_amd.scenes.refractive_scene() rounded to float32")
+            save(name, meta, skw, compact_full(res, 200, 150))
+            print(name, f"{time.time() - t0:.1f}s", flush=True)
 
     # --- C2..C4: sparse pixel subsets of the big frames ---------------------------------------
     cfgs = [

@@ -38,7 +38,8 @@ def golden_scene_arrays(g):
 def scene_dict_from_arrays(a):
     from raytracer_amd.scenes import scene_from_arrays
     return scene_from_arrays(a["center"], a["radius"], a["color"], a["specular"], a["reflection"],
-                             a["lights"], int(a["area_samples"]))
+                             a["lights"], int(a["area_samples"]), refraction=a.get("refraction"),
+                             refractive_index=a.get("refractive_index"))
 
 
 @pytest.fixture(scope="session")

@@ -177,6 +177,17 @@ def test_full_scale_multisample_and_noise_statistics(renderer, oracle):
     assert np.abs(gpu.mean(axis=0) - ref.mean(axis=0)).max(-1).mean() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["refr_glass_200x150_D5_spp2_modeK", "refr_glass_200x150_D3_spp1_modeC"])
+def test_refraction_against_reference_goldens(renderer, name):
+    """The refraction fixtures come from the reference itself (oracle/gen_golden.py)."""
+    g = load_golden(name)
+    m = g["meta"]
+    renderer.upload_scene(scene_dict_from_arrays(golden_scene_arrays(g)))
+    img = renderer.render(m["width"], m["height"], m["samples"], max_depth=m["max_depth"], rng_mode=m["mode"],
+                          seed=m["seed"]).cpu().numpy()
+    check_rgb(img, g["rgb8"])
+
+
 @pytest.mark.parametrize("w,h,D,spp,mode", [(320, 240, 5, 1, "K"), (333, 187, 5, 2, "K"), (160, 120, 2, 1, "C"),
                                             (640, 480, 8, 1, "K")])
 def test_refraction_against_oracle(renderer, oracle, w, h, D, spp, mode):

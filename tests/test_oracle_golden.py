@@ -22,13 +22,14 @@ def _run(oracle, g, pixels=None, **over):
     kw.update(over)
     return oracle.render_pixels(a["center"], a["radius"], a["color"], a["specular"], a["reflection"],
                                 a["lights"], int(a["area_samples"]), m["width"], m["height"],
-                                pixels=pixels, **kw)
+                                pixels=pixels, refraction=a.get("refraction"),
+                                refractive_index=a.get("refractive_index"), **kw)
 
 
 def test_all_fixtures_are_covered():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    known = set(SPARSE + PIN + ["c5_orbit_1920x1080_D5", "c1_default_640x480_D3_modeC",
-                                "c1_default_640x480_D3_modeK"])
+    known = set(SPARSE + PIN + REFR + ["c5_orbit_1920x1080_D5", "c1_default_640x480_D3_modeC",
+                                       "c1_default_640x480_D3_modeK"])
     assert set(names) == known
 
 
@@ -42,6 +43,26 @@ def test_sparse_fixtures_bit_exact(oracle, name):
     assert np.array_equal(o["trace_levels"], g["trace_levels"])
     assert np.array_equal(o["hit_levels"], g["hit_levels"])
     assert (g["hit"] >= 0).mean() > 0.5                    # the fixture is not mostly sky
+
+
+REFR = ["refr_glass_200x150_D5_spp2_modeK", "refr_glass_200x150_D3_spp1_modeC"]
+
+
+@pytest.mark.parametrize("name", REFR)
+def test_refraction_full_frames_bit_exact(oracle, name):
+    """compute_refraction (raytracer.py:213-230, :252-254) and the shadow rule of :187 / :202, from
+    the reference run on raytracer_amd.scenes.refractive_scene()."""
+    g = load_golden(name)
+    h, w = g["meta"]["height"], g["meta"]["width"]
+    assert (golden_scene_arrays(g)["refraction"] > 0).sum() == 3
+    o = _run(oracle, g)
+    assert np.array_equal(o["color"].reshape(h, w, 3), g["color"])
+    assert np.array_equal(o["rgb8"].reshape(h, w, 3), g["rgb8"])
+    assert np.array_equal(o["hit"].reshape(h, w), g["hit"])
+    assert np.array_equal(o["trace_levels"].reshape(h, w), g["trace_levels"])
+    assert np.array_equal(o["hit_levels"].reshape(h, w), g["hit_levels"])
+    # a refractive hit has two children: more levels per sample than the D + 1 of a chain
+    assert g["trace_levels"].max() > g["meta"]["samples"] * (g["meta"]["max_depth"] + 1)
 
 
 @pytest.mark.parametrize("name", PIN)
