@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|t64|c3|c1]
 
-One "step" = one batch of ``--frames`` (default 16) 1080p frames of BASELINE.json config 2
+One "step" = one batch of ``--frames`` (default 64, = one kernel launch pair) 1080p frames of BASELINE.json config 2
 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per shaded hit, keyed RNG, seed = frame
 index), inputs (scene) already resident on the GPU.  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=16, help="frames per step (batch)")
+    ap.add_argument("--frames", type=int, default=64, help="frames per step (batch)")
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--kernel", default="stream", choices=["stream", "pixel"])
@@ -182,7 +182,8 @@ def main():
     rc = r.ray_counts()
     stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    launches_per_step = -(-F // 16) * args.samples                            # <= 16 frames per launch
+    from raytracer_amd._lib import FRAMES_PER_LAUNCH
+    launches_per_step = -(-F // FRAMES_PER_LAUNCH) * args.samples
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
     kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
     if world > 1:

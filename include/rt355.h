@@ -28,6 +28,7 @@ extern "C" {
 #define RT_MAX_SPHERES 2048      /* 16 B of LDS per sphere in the shading kernels: 32 KiB      */
 #define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
 #define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
+#define RT_FRAMES_PER_LAUNCH 64  /* frames of a batch that share one kernel launch pair        */
 
 #define RT_OK 0
 #define RT_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned)          */
@@ -125,7 +126,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera* cam, int width, int height, int
                    int max_depth, int rng_mode, uint64_t seed, int tile_rows, int tile_first,
                    int tile_stride, uint8_t* out_rgb, int32_t* out_hit, int* n_local_rows_out);
 
-/* rt_render_rows for a batch of frames (frame f: cams[f], seeds[f]) of one uploaded scene, up to 16
+/* rt_render_rows for a batch of frames (frame f: cams[f], seeds[f]) of one uploaded scene, up to RT_FRAMES_PER_LAUNCH
  * frames per kernel launch.  Frame f is written at out_rgb + f * stride * 3 bytes (out_hit + f *
  * stride ints), stride = out_frame_stride_px pixels, or n_local_rows * width when that is 0.  This
  * is what a rank of a multi-GPU animation / benchmark batch calls (row tiles of every frame into

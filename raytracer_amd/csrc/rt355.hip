@@ -61,7 +61,9 @@ struct DevLights {
   float arad;   // 0.5 (|au| + |av|): every area-light sample lies within this distance of apos
 };
 
-constexpr int kMaxBatch = 16;  // frames per launch
+// frames per launch: the fixed cost of a launch pair (ramp-up, the stream kernel's uneven tail, the
+// gaps between dependent launches: ~0.1 ms) is paid once per batch — 16 -> 64 frames is +14 % on config 2
+constexpr int kMaxBatch = RT_FRAMES_PER_LAUNCH;
 struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
 
 struct RenderParams {
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
 //   * a wave whose counter runs dry moves to any counter a coherent load shows not to be exhausted.
 // ------------------------------------------------------------------------------------------
 constexpr int kPendingCap = 128;                      // <= 63 left over + one tile
-constexpr int kBounceCap = 128;                       // <= 63 queued + 64 pushed
+constexpr int kBounceCap = 64;                        // a pass takes ALL queued records (<= 64), then pushes <= 64
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
 #ifndef RT_RING
 #define RT_RING 4     // 4 keeps the kernel at 4 workgroups per CU up to 64 spheres (LDS); 8 and 16 measured no faster
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kCap * 4);
   int16_t* ring = reinterpret_cast<int16_t*>(pend + kPendingCap);               // [kRing][kVisTile] tile records
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
-  if (tid < kMaxBatch * 12) s_cams[tid] = (&p.cams[0].origin[0])[tid];
+  for (int i = tid; i < kMaxBatch * 12; i += kBlock) s_cams[i] = (&p.cams[0].origin[0])[i];
   if (tid < kMaxBatch) s_seeds[tid] = p.seeds[tid];
   __syncthreads();   // the only workgroup-wide synchronisation
 
