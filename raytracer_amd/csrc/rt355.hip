@@ -817,7 +817,9 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
 //     is brought in by LDS-direct loads (global_load_lds_dword: 2 tiles = 256 bytes per instruction,
 //     no registers held across the lighting loops) issued before a pass and read after it.  A
 //     wave's first tile is its own global wave number (no atomic at the start).
-//   * a wave whose counter runs dry moves to any counter a coherent load shows not to be exhausted.
+//   * a wave whose counter runs dry re-homes: one coherent load of all K counters, the next one
+//     that still has tiles becomes its counter, and claiming goes on there through the same
+//     pipelined, guided-size path (one-tile synchronous claims at the end cost 8-9 % at 64 spheres).
 // ------------------------------------------------------------------------------------------
 constexpr int kPendingCap = 128;                      // <= 63 left over + one tile
 constexpr int kBounceCap = 64;                        // a pass takes ALL queued records (<= 64), then pushes <= 64
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   // deals in tile ids only: no decoding into frame / row / column here)
   int cl_left = 0, cl_id = 0;      // slots of the current claim not yet started, tile id of the next one
   if (gwave < total_tiles) { cl_left = 1; cl_id = gwave; }
-  bool endgame = false;            // the home counter is exhausted: claims are made one tile at a time
+  bool homeless = false;           // the counter this wave drew from is exhausted: it must find another
   int pf_n = 0, pf_c = 0;          // the claim being requested (lane 0 receives the counter value)
   int nx_n = 0, nx_id = 0;         // the claim after the current one: slots, first tile id
   int seen = first_of(hcur);       // position of the home counter when this wave last looked
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           const unsigned long long t0 = RT_NOW();
           for (;;) {
             bool asked = false;
-            if (nx_n == 0 && !endgame && cl_left < kRing) {
+            if (nx_n == 0 && !homeless && cl_left < kRing) {
               pf_n = claim_size(hcur, seen);
               if (lane == 0) pf_c = atomicAdd(p.chunk_counter + hcur * 32, pf_n);
               asked = true;
@@ -933,23 +935,24 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             while (tail - head < uint32_t(kRing) && !supply_done) {
               if (cl_left == 0) {
                 if (nx_n > 0) { cl_left = nx_n; nx_n = 0; cl_id = nx_id; continue; }
-                if (!endgame) { stalled = true; break; }
-                // endgame: look (coherently) for a counter that still has tiles, claim one synchronously
-                int next = total_tiles;
-                if (lane < kTileCounters)
-                  next = (__hip_atomic_load(p.chunk_counter + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-                          first_of(lane)) * kTileCounters + lane;
-                const uint32_t avail = uint32_t(__ballot(next < total_tiles)) & ~dry;
-                if (avail == 0u) { supply_done = true; break; }
-                const uint32_t from = avail >> hcur;    // first candidate at or after hcur
-                hcur = from ? hcur + __ffs(int(from)) - 1 : __ffs(int(avail)) - 1;
-                int c2 = 0;
-                if (lane == 0) c2 = atomicAdd(p.chunk_counter + hcur * 32, 1);
-                c2 = __builtin_amdgcn_readfirstlane(c2);
-                const int id = (first_of(hcur) + c2) * kTileCounters + hcur;
-                if (id < total_tiles) { cl_left = 1; cl_id = id; }
-                else dry |= 1u << hcur;
-                continue;
+                if (homeless) {
+                  // look (coherently) at all counters and move in with the first one, at or after the
+                  // old home, that still has tiles; claims there go on through the same pipeline
+                  int next = total_tiles, pos = 0;
+                  if (lane < kTileCounters) {
+                    pos = __hip_atomic_load(p.chunk_counter + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                          first_of(lane);
+                    next = pos * kTileCounters + lane;
+                  }
+                  const uint32_t avail = uint32_t(__ballot(next < total_tiles)) & ~dry;
+                  if (avail == 0u) { supply_done = true; break; }
+                  const uint32_t from = avail >> hcur;
+                  hcur = from ? hcur + __ffs(int(from)) - 1 : __ffs(int(avail)) - 1;
+                  seen = __builtin_amdgcn_readlane(pos, hcur);
+                  homeless = false;
+                }
+                stalled = true;                // ask (again) at the top of the refill loop
+                break;
               }
               if (cl_id >= total_tiles) { cl_left = 0; continue; }   // the rest of this claim lies beyond the end
               // ---- issue the tile: 36 lanes x 4 bytes (indices + header) straight into ring[slot]
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
               const int slot = first_of(hcur) + __builtin_amdgcn_readfirstlane(pf_c);
               seen = slot + pf_n;
               if (slot * kTileCounters + hcur < total_tiles) { nx_n = pf_n; nx_id = slot * kTileCounters + hcur; }
-              else { endgame = true; dry |= 1u << hcur; }
+              else { homeless = true; dry |= 1u << hcur; }
             }
             if (!stalled) break;               // else: go round again with the claim that has just landed
           }
