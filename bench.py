@@ -39,6 +39,10 @@ WORKLOADS = {
     "c2": (1920, 1080, 8, 1, True, 5, "config 2: 1920x1080, 8-sphere scene, depth 5, shadow rays"),
     "t64": (1920, 1080, 64, 2, False, 5, "north-star target: 1920x1080, 64 spheres, depth 5"),
     "c3": (3840, 2160, 64, 2, False, 8, "config 3: 3840x2160, 64 spheres, depth 8"),
+    # SURVEY.md 8(f) rows measured beside the headline (not bench lines of BASELINE.json)
+    "refr": (1920, 1080, 5, 0, True, 5, "8f rank 2: refractive_scene() (default scene + glass) 1920x1080 depth 5"),
+    "cubes": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene() (default scene + 3 opaque cubes) 1920x1080 depth 5"),
+    "cubes_glass": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene(glass=True) 1920x1080 depth 5"),
 }
 
 
@@ -50,8 +54,10 @@ def algorithmic_flops(rays: int, shaded: int, n_spheres: int, area_samples: int)
 
 
 def build_scene(wl):
-    from raytracer_amd.scenes import default_scene, generate_scene
+    from raytracer_amd.scenes import cube_scene, default_scene, generate_scene, refractive_scene
     w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
+    if wl in ("refr", "cubes", "cubes_glass"):
+        return refractive_scene() if wl == "refr" else cube_scene(glass=(wl == "cubes_glass"))
     return default_scene() if n == 3 else generate_scene(n, sseed, w, h, keep_default=keep)
 
 
@@ -70,9 +76,8 @@ def cpu_baseline(wl, target_s=15.0):
 
     def run_frame(seed, nthreads=None):
         t0 = time.perf_counter()
-        o = cpu_oracle.render_pixels(p.geom4[:, :3], p.radius, p.mat4[:, :3], p.spec, p.mat4[:, 3],
-                                     p.lights, p.area_samples, w, h, max_depth=D, mode="K", seed=seed,
-                                     threads=threads if nthreads is None else nthreads)
+        o = cpu_oracle.render_scene(p, w, h, max_depth=D, mode="K", seed=seed,
+                                    threads=threads if nthreads is None else nthreads)
         dt = time.perf_counter() - t0
         rays = int(o["trace_levels"].sum()) + (1 + p.area_samples) * int(o["hit_levels"].sum())
         return rays, dt

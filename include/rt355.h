@@ -107,6 +107,24 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
  * RT_KERNEL_PIXEL is refused. */
 int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refractive_index, int n_spheres);
 
+/* Cube objects (raytracer.py:56-60) in the list find_nearest_intersection scans (:156-160, :164-169):
+ * intersect_cube (:106-137) and cube_normal (:142-150).  n_cubes boxes, host pointers:
+ *   box6[n][6] = min_point xyz, max_point xyz     mat4[n][4] = R, G, B, reflection     spec[n] = specular
+ *   refraction[n], refractive_index[n]: Material's, or NULL for the defaults 0 / 1.
+ * The cubes become objects n_spheres, n_spheres + 1, ... of the scene (the hit index of out_hit); the
+ * host mirror (raytracer_amd.scenes.pack_scene) maps these back to positions in the reference's list.
+ * A sphere wins an exact tie in t against a cube here whatever their list order (the reference keeps
+ * the earlier list member, :162); such ties have measure zero.  rt_upload_scene resets the scene to no
+ * cubes; call this after it.  n_spheres + 2 n_cubes <= RT_MAX_SPHERES.  RT_KERNEL_PIXEL is refused
+ * while cubes are present.
+ * The reference's behaviour is reproduced as it is, not as a box should look: intersect_cube returns
+ * t_max unchecked when t_min <= 0 (:137) and :162 accepts any non-zero t, so a cube is hit by every
+ * ray whose LINE passes through it, also behind the origin (t < 0, which then beats every sphere).
+ * An opaque cube therefore shadows itself completely and every point whose line to a light crosses
+ * it in either direction. */
+int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float* spec, const float* refraction,
+                 const float* refractive_index, int n_cubes);
+
 /* render(width, height, samples) (raytracer.py:310-325): the whole frame.
  *   out_rgb: device uint8 [height][width][3], row 0 = top, tightly packed — the array the
  *            reference returns and hands to glTexImage2D (raytracer.py:346).

@@ -29,6 +29,7 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _lib.rto_render_pixels.restype = ctypes.c_int
         _lib.rto_render_pixels2.restype = ctypes.c_int
+        _lib.rto_render_objects.restype = ctypes.c_int
         _lib.rto_max_threads.restype = ctypes.c_int
     return _lib
 
@@ -39,8 +40,12 @@ def _p(a, ct):
 
 def render_pixels(center, radius, color, specular, reflection, lights, area_samples, width, height,
                   pixels=None, samples=1, max_depth=5, mode="K", seed=0, camera=None,
-                  precision="f64", threads=0, refraction=None, refractive_index=None):
+                  precision="f64", threads=0, refraction=None, refractive_index=None, kind=None,
+                  box_max=None):
     """Render the listed (x, y) pixels (or the full frame if ``pixels`` is None).
+
+    ``kind`` / ``box_max``: objects in the reference's list order, kind 0 = sphere (center, radius),
+    1 = cube (``center`` holds min_point, ``box_max`` max_point); None = all spheres.
 
     Scene arrays are float32 (the values the kernel gets); the oracle widens them to double.
     Returns dict(color f64[n,3], rgb8 u8[n,3], hit i32[n], trace_levels i64[n], hit_levels i64[n],
@@ -57,6 +62,9 @@ def render_pixels(center, radius, color, specular, reflection, lights, area_samp
     refractive_index = None if refractive_index is None else f32(refractive_index).ravel()
     assert refraction is None or len(refraction) == n
     assert refractive_index is None or len(refractive_index) == n
+    kind = None if kind is None else np.ascontiguousarray(kind, np.int32).ravel()
+    box_max = None if box_max is None else f32(box_max).reshape(-1, 3)
+    assert kind is None or (len(kind) == n and box_max is not None and box_max.shape == (n, 3))
     cam = f32(DEFAULT_CAMERA if camera is None else camera).reshape(12)
     if pixels is None:
         px, npx = None, width * height
@@ -66,8 +74,8 @@ def render_pixels(center, radius, color, specular, reflection, lights, area_samp
     out = dict(color=np.zeros((npx, 3)), rgb8=np.zeros((npx, 3), np.uint8),
                hit=np.zeros(npx, np.int32), trace_levels=np.zeros(npx, np.int64),
                hit_levels=np.zeros(npx, np.int64), margin=np.zeros(npx))
-    rc = L.rto_render_pixels2(
-        ctypes.c_int(n), _p(center, ctypes.c_float), _p(radius, ctypes.c_float),
+    rc = L.rto_render_objects(
+        ctypes.c_int(n), _p(kind, ctypes.c_int32), _p(box_max, ctypes.c_float), _p(center, ctypes.c_float), _p(radius, ctypes.c_float),
         _p(color, ctypes.c_float), _p(specular, ctypes.c_float), _p(reflection, ctypes.c_float),
         _p(refraction, ctypes.c_float), _p(refractive_index, ctypes.c_float),
         _p(lights, ctypes.c_float), ctypes.c_int(int(area_samples)), _p(cam, ctypes.c_float),
@@ -84,14 +92,15 @@ def render_pixels(center, radius, color, specular, reflection, lights, area_samp
 
 def render_scene(scene: dict, width, height, **kw):
     """Same, from a raytracer_amd-style scene dict (uses raytracer_amd.scenes only to flatten it)."""
-    from raytracer_amd.scenes import pack_scene
-    p = pack_scene(scene)
+    from raytracer_amd.scenes import PackedScene, pack_scene
+    p = scene if isinstance(scene, PackedScene) else pack_scene(scene)
     cam = kw.pop("camera", None)
     if cam is not None and hasattr(cam, "as_array"):
         cam = cam.as_array()
-    return render_pixels(p.geom4[:, :3], p.radius, p.mat4[:, :3], p.spec, p.mat4[:, 3], p.lights,
-                         p.area_samples, width, height, camera=cam, refraction=p.refr[:, 0],
-                         refractive_index=p.refr[:, 1], **kw)
+    o = p.objects_in_list_order()      # hit indices are positions in the scene's object list
+    return render_pixels(o["p0"], o["radius"], o["mat4"][:, :3], o["spec"], o["mat4"][:, 3], p.lights,
+                         p.area_samples, width, height, camera=cam, refraction=o["refr"][:, 0],
+                         refractive_index=o["refr"][:, 1], kind=o["kind"], box_max=o["p1"], **kw)
 
 
 def max_threads() -> int:

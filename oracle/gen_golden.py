@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import cpu_oracle, ref_harness  # noqa: E402
-from raytracer_amd.scenes import (refractive_scene, Camera, default_scene, generate_scene, orbit_camera,  # noqa: E402
+from raytracer_amd.scenes import (cube_scene, refractive_scene, Camera, default_scene, generate_scene, orbit_camera,  # noqa: E402
                                  pack_scene)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -43,11 +43,18 @@ def _scene_from_kw(kw):
     from raytracer_amd.scenes import scene_from_arrays
     return scene_from_arrays(kw["center"], kw["radius"], kw["color"], kw["specular"],
                              kw["reflection"], kw["lights"], kw["area_samples"],
-                             refraction=kw.get("refraction"), refractive_index=kw.get("refractive_index"))
+                             refraction=kw.get("refraction"), refractive_index=kw.get("refractive_index"),
+                             kind=kw.get("kind"), box_max=kw.get("box_max"))
 
 
 def scene_kw(scene):
     p = pack_scene(scene)
+    if p.n_cubes:      # the object list in the reference's order: center = min_point for cubes
+        o = p.objects_in_list_order()
+        return dict(center=o["p0"].copy(), radius=o["radius"].copy(), color=o["mat4"][:, :3].copy(),
+                    specular=o["spec"].copy(), reflection=o["mat4"][:, 3].copy(), lights=p.lights.copy(),
+                    area_samples=p.area_samples, refraction=o["refr"][:, 0].copy(),
+                    refractive_index=o["refr"][:, 1].copy(), kind=o["kind"].copy(), box_max=o["p1"].copy())
     return dict(center=p.geom4[:, :3].copy(), radius=p.radius.copy(), color=p.mat4[:, :3].copy(),
                 specular=p.spec.copy(), reflection=p.mat4[:, 3].copy(), lights=p.lights.copy(),
                 area_samples=p.area_samples,
@@ -178,6 +185,19 @@ def main():
             res = run_reference(pool, skw, 200, 150, px, spp, D, mode, 3)
             meta = dict(width=200, height=150, samples=spp, max_depth=D, mode=mode, seed=3,
                         scene="raytracer_amd.scenes.refractive_scene() rounded to float32")
+            save(name, meta, skw, compact_full(res, 200, 150))
+            print(name, f"{time.time() - t0:.1f}s", flush=True)
+
+    # --- cubes: Cube objects in the reference's object list ---------------------
+    for glass, mode, D, spp in ((False, "K", 5, 2), (True, "C", 3, 1), (True, "K", 5, 1)):
+        name = f"cube_{'glass' if glass else 'opaque'}_200x150_D{D}_spp{spp}_mode{mode}"
+        if want(name):
+            t0 = time.time()
+            skw = scene_kw(cube_scene(glass))
+            px = full_frame_pixels(200, 150)
+            res = run_reference(pool, skw, 200, 150, px, spp, D, mode, 5)
+            meta = dict(width=200, height=150, samples=spp, max_depth=D, mode=mode, seed=5,
+                        scene=f"raytracer_amd.scenes.cube_scene(glass={glass}) rounded to float32")
             save(name, meta, skw, compact_full(res, 200, 150))
             print(name, f"{time.time() - t0:.1f}s", flush=True)
 

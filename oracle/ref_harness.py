@@ -184,18 +184,22 @@ def to_ref_scene(ref, scene: dict) -> dict:
     def v(a):
         return V(f(a.x), f(a.y), f(a.z))
 
+    def mat(m):
+        return ref.Material(v(m.color), specular=f(m.specular), reflection=f(m.reflection),
+                            refraction=f(getattr(m, "refraction", 0)),
+                            refractive_index=f(getattr(m, "refractive_index", 1)))
+
+    def obj(s):      # the reference's own classes: find_nearest_intersection dispatches on them (:157)
+        if hasattr(s, "min_point"):
+            return ref.Cube(v(s.min_point), v(s.max_point), mat(s.material))
+        return ref.Sphere(v(s.center), f(s.radius), mat(s.material))
+
     pl, al = scene["global_light"], scene["area_light"]
     return {
         "global_light": ref.Light(v(pl.position), v(pl.color), f(pl.intensity)),
         "area_light": ref.AreaLight(v(al.position), v(al.u), v(al.v), v(al.color),
                                     f(al.intensity), samples=int(al.samples)),
-        "spheres": [ref.Sphere(v(s.center), f(s.radius),
-                               ref.Material(v(s.material.color),
-                                            specular=f(s.material.specular),
-                                            reflection=f(s.material.reflection),
-                                            refraction=f(getattr(s.material, "refraction", 0)),
-                                            refractive_index=f(getattr(s.material, "refractive_index", 1))))
-                    for s in scene["spheres"]],
+        "spheres": [obj(s) for s in scene["spheres"]],
     }
 
 

@@ -43,7 +43,9 @@ template <typename T> inline V3<T> normalize(V3<T> a) {                         
 template <typename T>
 struct SceneT {
   int n = 0;
-  std::vector<V3<T>> center, color;
+  std::vector<V3<T>> center, color;   // center: Sphere.center, or Cube.min_point (:58)
+  std::vector<V3<T>> box_max;         // Cube.max_point (:59); unused for spheres
+  std::vector<int> kind;              // 0 = Sphere (:50-54), 1 = Cube (:56-60): the isinstance() of :157, :164
   std::vector<T> radius, specular, reflection, refraction, refractive_index;
   V3<T> p_pos, p_col; T p_int;                       // scene['global_light'], :79
   V3<T> a_pos, a_u, a_v, a_col; T a_int; int a_samples;  // scene['area_light'], :80
@@ -91,10 +93,49 @@ inline bool intersect_sphere(V3<T> o, V3<T> d, V3<T> c, T radius, T* t_out, doub
   return true;
 }
 
+// intersect_cube, raytracer.py:106-137. Returns false for `None`; *t_out may be negative or zero (the
+// reference returns t_max unchecked when t_min <= 0, :137 — a box wholly behind the origin yields t < 0,
+// which find_nearest_intersection's `if t and t < min_distance` (:162) ACCEPTS).
+template <typename T>
+inline bool intersect_cube(V3<T> o, V3<T> d, V3<T> lo, V3<T> hi, T* t_out) {
+  T t_min = -std::numeric_limits<T>::infinity();          // :107
+  T t_max = std::numeric_limits<T>::infinity();           // :108
+  const T mins[3] = {lo.x, lo.y, lo.z}, maxs[3] = {hi.x, hi.y, hi.z};
+  const T org[3] = {o.x, o.y, o.z}, dir[3] = {d.x, d.y, d.z};
+  for (int i = 0; i < 3; ++i) {                           // :110-122
+    if (std::fabs(dir[i]) < T(1e-8)) {                    // :124
+      if (org[i] < mins[i] || org[i] > maxs[i]) return false;   // :125-126
+    } else {
+      T t1 = (mins[i] - org[i]) / dir[i];                 // :128
+      T t2 = (maxs[i] - org[i]) / dir[i];                 // :129
+      if (t1 > t2) { T tmp = t1; t1 = t2; t2 = tmp; }     // :130-131
+      if (t1 > t_min) t_min = t1;                         // :132  max(t_min, t1)
+      if (t2 < t_max) t_max = t2;                         // :133  min(t_max, t2)
+      if (t_min > t_max) return false;                    // :134-135
+    }
+  }
+  *t_out = t_min > 0 ? t_min : t_max;                     // :137
+  return true;
+}
+
+// cube_normal, raytracer.py:142-150
+template <typename T>
+inline V3<T> cube_normal(V3<T> lo, V3<T> hi, V3<T> p) {
+  const T eps = T(1e-5);                                  // :143
+  if (std::fabs(p.x - lo.x) < eps) return {-1, 0, 0};     // :144
+  if (std::fabs(p.x - hi.x) < eps) return {1, 0, 0};      // :145
+  if (std::fabs(p.y - lo.y) < eps) return {0, -1, 0};     // :146
+  if (std::fabs(p.y - hi.y) < eps) return {0, 1, 0};      // :147
+  if (std::fabs(p.z - lo.z) < eps) return {0, 0, -1};     // :148
+  if (std::fabs(p.z - hi.z) < eps) return {0, 0, 1};      // :149
+  return {0, 1, 0};                                       // :150
+}
+
 template <typename T>
 struct Hit { int idx; V3<T> point, normal; };
 
-// find_nearest_intersection, raytracer.py:152-172 (spheres only: :156 iterates scene['spheres'])
+// find_nearest_intersection, raytracer.py:152-172: :156 iterates scene['spheres'], whose members are
+// dispatched on their type (:157-160, :164-169), so a Cube placed in that list is traced.
 template <typename T>
 inline bool find_nearest(const SceneT<T>& s, V3<T> o, V3<T> d, Hit<T>* h, double* margin) {
   bool found = false;
@@ -102,6 +143,17 @@ inline bool find_nearest(const SceneT<T>& s, V3<T> o, V3<T> d, Hit<T>* h, double
   T second = std::numeric_limits<T>::infinity();
   for (int i = 0; i < s.n; ++i) {                         // :156
     T t;
+    if (s.kind[i] == 1) {                                 // :159-160
+      if (!intersect_cube(o, d, s.center[i], s.box_max[i], &t)) continue;
+      if (t != T(0) && t < min_distance) {                // :162
+        min_distance = t;
+        V3<T> p = add(o, muls(d, t));                     // :168
+        h->idx = i; h->point = p;
+        h->normal = cube_normal(s.center[i], s.box_max[i], p);   // :169
+        found = true;
+      }
+      continue;
+    }
     if (!intersect_sphere(o, d, s.center[i], s.radius[i], &t, margin)) continue;
     if (margin && t != T(0)) { if (t < min_distance) second = min_distance; else if (t < second) second = t; }
     if (t != T(0) && t < min_distance) {                  // :162  `if t and t < min_distance`
@@ -239,12 +291,18 @@ V3<T> render_pixel(const SceneT<T>& s, int x, int y, int width, int height, int 
 }
 
 template <typename T>
-void build_scene(SceneT<T>& s, int n, const float* center, const float* radius, const float* color,
+void build_scene(SceneT<T>& s, int n, const int32_t* kind, const float* box_max, const float* center,
+                 const float* radius, const float* color,
                  const float* specular, const float* reflection, const float* refraction,
                  const float* refractive_index, const float* lights, int area_samples, const float* camera) {
   s.n = n;
   s.center.resize(n); s.color.resize(n); s.radius.resize(n); s.specular.resize(n); s.reflection.resize(n);
   s.refraction.assign(n, T(0)); s.refractive_index.assign(n, T(1));   // Material defaults, :43
+  s.kind.assign(n, 0); s.box_max.assign(n, V3<T>{0, 0, 0});
+  for (int i = 0; i < n; ++i) {
+    if (kind) s.kind[i] = kind[i];
+    if (box_max) s.box_max[i] = {T(box_max[3 * i]), T(box_max[3 * i + 1]), T(box_max[3 * i + 2])};
+  }
   for (int i = 0; i < n; ++i) {
     if (refraction) s.refraction[i] = T(refraction[i]);
     if (refractive_index) s.refractive_index[i] = T(refractive_index[i]);
@@ -262,14 +320,14 @@ void build_scene(SceneT<T>& s, int n, const float* center, const float* radius, 
 }
 
 template <typename T>
-int run(int n, const float* center, const float* radius, const float* color, const float* specular,
+int run(int n, const int32_t* kind, const float* box_max, const float* center, const float* radius, const float* color, const float* specular,
         const float* reflection, const float* refraction, const float* refractive_index,
         const float* lights, int area_samples, const float* camera,
         int width, int height, const int32_t* pixels, int64_t n_pixels, int samples, int D, int mode,
         uint64_t seed, int threads, double* out_color, uint8_t* out_rgb8, int32_t* out_hit,
         int64_t* out_trace_levels, int64_t* out_hit_levels, double* out_margin) {
   SceneT<T> s;
-  build_scene(s, n, center, radius, color, specular, reflection, refraction, refractive_index, lights,
+  build_scene(s, n, kind, box_max, center, radius, color, specular, reflection, refraction, refractive_index, lights,
               area_samples, camera);
   uint32_t seed32 = uint32_t(seed ^ (seed >> 32));
   if (!pixels) n_pixels = int64_t(width) * height;
@@ -303,7 +361,10 @@ extern "C" {
 // precision: 0 = double (the oracle), 1 = float (diagnostic).  pixels = NULL renders the full
 // frame row-major.  Outputs may be NULL.  `hit`/`margin` refer to the LAST sample's primary ray.
 // refraction / refractive_index: per sphere, or NULL for the Material defaults 0 / 1 (raytracer.py:43).
-int rto_render_pixels2(int n, const float* center, const float* radius, const float* color,
+// kind / box_max: per object of the list the reference scans (:156), in list order: kind 0 = Sphere
+// (center, radius), 1 = Cube (center holds min_point, box_max max_point); NULL = all spheres.
+int rto_render_objects(int n, const int32_t* kind, const float* box_max, const float* center,
+                       const float* radius, const float* color,
                        const float* specular, const float* reflection, const float* refraction,
                        const float* refractive_index, const float* lights,
                        int area_samples, const float* camera, int width, int height,
@@ -313,12 +374,26 @@ int rto_render_pixels2(int n, const float* center, const float* radius, const fl
                        int64_t* out_hit_levels, double* out_margin) {
   if (n < 0 || width <= 0 || height <= 0 || samples <= 0 || area_samples <= 0) return -1;
   if (precision == 0)
-    return run<double>(n, center, radius, color, specular, reflection, refraction, refractive_index, lights,
+    return run<double>(n, kind, box_max, center, radius, color, specular, reflection, refraction, refractive_index, lights,
                        area_samples, camera, width, height, pixels, n_pixels, samples, max_depth, mode, seed,
                        threads, out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
-  return run<float>(n, center, radius, color, specular, reflection, refraction, refractive_index, lights,
+  return run<float>(n, kind, box_max, center, radius, color, specular, reflection, refraction, refractive_index, lights,
                     area_samples, camera, width, height, pixels, n_pixels, samples, max_depth, mode, seed,
                     threads, out_color, out_rgb8, out_hit, out_trace_levels, out_hit_levels, out_margin);
+}
+
+int rto_render_pixels2(int n, const float* center, const float* radius, const float* color,
+                       const float* specular, const float* reflection, const float* refraction,
+                       const float* refractive_index, const float* lights,
+                       int area_samples, const float* camera, int width, int height,
+                       const int32_t* pixels, int64_t n_pixels, int samples, int max_depth, int mode,
+                       uint64_t seed, int precision, int threads, double* out_color,
+                       uint8_t* out_rgb8, int32_t* out_hit, int64_t* out_trace_levels,
+                       int64_t* out_hit_levels, double* out_margin) {
+  return rto_render_objects(n, nullptr, nullptr, center, radius, color, specular, reflection, refraction,
+                            refractive_index, lights, area_samples, camera, width, height, pixels, n_pixels,
+                            samples, max_depth, mode, seed, precision, threads, out_color, out_rgb8, out_hit,
+                            out_trace_levels, out_hit_levels, out_margin);
 }
 
 int rto_render_pixels(int n, const float* center, const float* radius, const float* color,

@@ -84,6 +84,8 @@ struct RenderParams {
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
   const float2* refr;    // refraction, refractive_index (raytracer.py:43); only read by the REFR kernels
+  const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
+  int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
   int16_t* vis;            // [frame][tiles8_y][tiles8_x][kVisTile] per 8x8 tile: 64 primary hit indices (-1 = miss /
@@ -239,6 +241,113 @@ __device__ __forceinline__ float sphere_t_exact(const float4 s, float ox, float 
   return q - fsqrt(dl * inv_a);
 }
 
+// ------------------------------------------------------------------------------------------
+// Cubes: members of scene['spheres'] that are not Sphere objects go through
+// intersect_cube / cube_normal (raytracer.py:157-160, :164-169).
+//
+// intersect_cube (:106-137), slab test.  `inv` = 1/d per axis, only used where |d| >= 1e-8 (:124).
+// Returns whether find_nearest_intersection would consider the result (`if t and ...`, :162), i.e. not
+// None and not 0.  As in the reference, t is t_max WITHOUT a sign check when t_min <= 0 (:137): a box
+// behind the origin yields t < 0 and is accepted by :162 (`t < min_distance`), so it beats every sphere.
+// `face` = 2 * axis + (0: min plane, 1: max plane) names the plane that produced t.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cube_t(const float4 lo, const float4 hi, float ox, float oy, float oz, float dx,
+                                       float dy, float dz, float ix, float iy, float iz, float& t, int& face) {
+  float tmin = -INFINITY, tmax = INFINITY;                        // :107-108
+  int fmin = 0, fmax = 0;
+  bool ok = true;
+  auto axis = [&](float o, float d, float inv, float mn, float mx, int a) {
+    if (fabsf(d) < 1e-8f) {                                       // :124-126
+      ok = ok && !(o < mn || o > mx);
+    } else {
+      float t1 = (mn - o) * inv, t2 = (mx - o) * inv;             // :128-129
+      int f1 = 2 * a, f2 = 2 * a + 1;
+      if (t1 > t2) { const float tt = t1; t1 = t2; t2 = tt; f1 = 2 * a + 1; f2 = 2 * a; }   // :130-131
+      if (t1 > tmin) { tmin = t1; fmin = f1; }                    // :132
+      if (t2 < tmax) { tmax = t2; fmax = f2; }                    // :133
+    }
+  };
+  axis(ox, dx, ix, lo.x, hi.x, 0);
+  axis(oy, dy, iy, lo.y, hi.y, 1);
+  axis(oz, dz, iz, lo.z, hi.z, 2);
+  // (:134-135 tests t_min > t_max after every axis; t_min only grows and t_max only shrinks, so
+  // testing once at the end decides the same)
+  if (!ok || tmin > tmax) return false;
+  t = tmin > 0.0f ? tmin : tmax;                                  // :137
+  face = tmin > 0.0f ? fmin : fmax;
+  return t != 0.0f;
+}
+
+// Hit point on a cube (:168): o + d t, with the coordinate of the plane that was hit set to the plane
+// itself.  In the reference's FP64 that coordinate is the plane's to ~1e-16 and cube_normal's
+// `abs(...) < 1e-5` (:144-149) recognises it; FP32's o + d t can be off by more than 1e-5 when the
+// origin is far away, so the plane is taken directly.
+__device__ __forceinline__ void snap_to_face(const float4 lo, const float4 hi, int face, float& px, float& py,
+                                             float& pz) {
+  const float4 s = (face & 1) ? hi : lo;
+  const int a = face >> 1;
+  if (a == 0) px = s.x; else if (a == 1) py = s.y; else pz = s.z;
+}
+
+// cube_normal (:142-150): the first face, in the reference's order, within 1e-5 of the point
+__device__ __forceinline__ void cube_normal(const float4 lo, const float4 hi, float px, float py, float pz,
+                                            float& nx, float& ny, float& nz) {
+  const float eps = 1e-5f;
+  nx = 0.f; ny = 1.f; nz = 0.f;                                   // :150
+  if (fabsf(px - lo.x) < eps) { nx = -1.f; ny = 0.f; }            // :144
+  else if (fabsf(px - hi.x) < eps) { nx = 1.f; ny = 0.f; }        // :145
+  else if (fabsf(py - lo.y) < eps) { ny = -1.f; }                 // :146
+  else if (fabsf(py - hi.y) < eps) { ny = 1.f; }                  // :147
+  else if (fabsf(pz - lo.z) < eps) { ny = 0.f; nz = -1.f; }       // :148
+  else if (fabsf(pz - hi.z) < eps) { ny = 0.f; nz = 1.f; }        // :149
+}
+
+// find_nearest_intersection (:152-172) over spheres AND cubes.  `sg` holds the n spheres followed by
+// the cubes (two entries each).  The spheres are scanned first: a cube listed before a sphere in the
+// reference's list wins an exact tie in t there and loses it here (ties between a sphere and a cube
+// have measure zero; include/rt355.h, rt_set_cubes).
+template <bool CUBES>
+__device__ __forceinline__ void nearest_object(const float4* __restrict__ sg, const float4* __restrict__ gg, int n,
+                                               int nc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               float& best_t, int& best_i, int& best_face) {
+  nearest_hit(sg, gg, n, ox, oy, oz, dx, dy, dz, best_t, best_i);
+  best_face = 0;
+  if constexpr (CUBES) {
+    const float ix = frcp(dx), iy = frcp(dy), iz = frcp(dz);
+    for (int c = 0; c < nc; ++c) {
+      float t;
+      int face;
+      if (cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], ox, oy, oz, dx, dy, dz, ix, iy, iz, t, face) && t < best_t) {
+        best_t = t; best_i = n + c; best_face = face;             // :162-163
+      }
+    }
+  }
+}
+
+// point = ray.origin + ray.direction * t (:165 / :168) of object idx
+template <bool CUBES>
+__device__ __forceinline__ void hit_point(const float4* __restrict__ sg, int n, int idx, int face, float ox,
+                                          float oy, float oz, float dx, float dy, float dz, float t, float& px,
+                                          float& py, float& pz) {
+  px = fmaf(dx, t, ox); py = fmaf(dy, t, oy); pz = fmaf(dz, t, oz);
+  if constexpr (CUBES)
+    if (idx >= n) snap_to_face(sg[n + 2 * (idx - n)], sg[n + 2 * (idx - n) + 1], face, px, py, pz);
+}
+
+// sphere_normal (:139-140) or cube_normal (:142-150) of object idx at P
+template <bool CUBES>
+__device__ __forceinline__ void surface_normal(const float4* __restrict__ sg, int n, int idx, float px, float py,
+                                               float pz, float& nx, float& ny, float& nz) {
+  if (CUBES && idx >= n) {
+    cube_normal(sg[n + 2 * (idx - n)], sg[n + 2 * (idx - n) + 1], px, py, pz, nx, ny, nz);
+  } else {
+    const float4 s = sg[idx];
+    nx = px - s.x; ny = py - s.y; nz = pz - s.z;
+    const float inv = frsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+    nx *= inv; ny *= inv; nz *= inv;
+  }
+}
+
 // table entry: four spheres, struct-of-arrays, so one s_load_dwordx16 brings a group and packed
 // VALU ops find sphere pairs in adjacent SGPRs.  w holds -c (or -inf where the camera is inside).
 struct __attribute__((aligned(64))) CamGroup {
@@ -352,9 +461,9 @@ static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigne
   atomicAdd(&g_dbg[0], (unsigned long long)r); atomicAdd(&g_dbg[1], (unsigned long long)l); atomicAdd(&g_dbg[2], (unsigned long long)i);
 }
 #endif
-template <int MODE, int B, bool REFR = false>
+template <int MODE, int B, bool REFR = false, bool CUBES = false>
 __device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg,
-                                         const float4* __restrict__ gg, const float2* __restrict__ refr, int n,
+                                         const float4* __restrict__ gg, const float2* __restrict__ refr, int n, int nc,
                                          float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          float mr, float mg, float mb, float spec, uint32_t level_key,
@@ -441,8 +550,8 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
       for (int k = 0; k < B; ++k) {
         if (base + k < nrays) {
           float t;
-          int hi;
-          nearest_hit(sg, gg, n, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi);
+          int hi, face;
+          nearest_object<CUBES>(sg, gg, n, nc, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi, face);
           const bool blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
           m[k] = blocked ? 0.0f : -1.0f;
         }
@@ -545,6 +654,22 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
 #pragma unroll 2
     for (int i = 0; i < n; ++i) test_sphere(sg[i]);
 #endif
+    if constexpr (CUBES && !REFR) {
+      // any-hit over the cubes: the ray is blocked if intersect_cube gives a non-zero t of EITHER sign
+      // (:137, :162 — see cube_t), so every cube is tested for every ray, ray by ray (three reciprocals
+      // per ray, shared by all cubes)
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const float ix = frcp(Lx[k]), iy = frcp(Ly[k]), iz = frcp(Lz[k]);
+        bool hit = false;
+        for (int c = 0; c < nc; ++c) {
+          float t;
+          int face;
+          hit = hit || cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], sx, sy, sz, Lx[k], Ly[k], Lz[k], ix, iy, iz, t, face);
+        }
+        if (hit) m[k] = 0.0f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < B; ++k) {
       const float ndl = fmaf(nz, Lz[k], fmaf(ny, Ly[k], nx * Lx[k]));
@@ -583,24 +708,20 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
 struct NoLateState {
   __device__ __forceinline__ void operator()() const {}
 };
-template <int MODE, typename LateState = NoLateState>
+template <int MODE, bool CUBES = false, typename LateState = NoLateState>
 __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* __restrict__ sg, int idx,
                                           float px, float py, float pz, float& dx, float& dy, float& dz,
                                           uint32_t level_key, float& tr, float& tg, float& tb,
                                           float& ar, float& ag, float& ab, float& ox, float& oy,
                                           float& oz, LateState load_state = LateState()) {
-  const float4 s = sg[idx];
   const float4 m = p.mat[idx];
   const float spec = p.spec[idx];
-  float nx = px - s.x, ny = py - s.y, nz = pz - s.z;               // :139-140
-  {
-    const float inv = frsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
-    nx *= inv; ny *= inv; nz *= inv;
-  }
+  float nx, ny, nz;
+  surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
   float lr, lg, lb;
-  lighting<MODE, kShadowBatch>(p.L, sg, p.geom, nullptr, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+  lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                m.x, m.y, m.z, spec, level_key, lr, lg, lb);
   load_state();
   const float refl = m.w;
@@ -725,7 +846,7 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
 // profiles/r1_ubench_issue_mix.txt), so it has no LDS staging, no barrier and no per-lane divisions:
 // the packed RGB rows of a tile (24 B each) are assembled across lanes with ds_bpermute.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool CUBES>
 __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderParams p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
@@ -748,6 +869,18 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
     primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + lx, y, p.sample_index, pixel_key, dx, dy, dz);
     primary_hit(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
                 cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+    if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
+      cgeom_t cg = as_const(p.cubes);
+      const float ix = frcp(dx), iy = frcp(dy), iz = frcp(dz);
+      for (int c = 0; c < p.n_cubes; ++c) {
+        float tc;
+        int face;
+        if (cube_t(cg[2 * c], cg[2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, ix, iy, iz,
+                   tc, face) && tc < t) {
+          t = tc; idx = p.n_spheres + c;
+        }
+      }
+    }
     if (p.out_hit && last_sample) p.out_hit[frame_px + wpix] = idx;
     if (idx < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
       finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &rgbx);
@@ -834,7 +967,7 @@ constexpr int kTileCounters = 32;
 #endif
 constexpr int kClaimMax = RT_CLAIM;
 
-constexpr int kBounceCapRefr = 192;                   // refraction: <= 63 queued + 2 x 64 pushed
+constexpr int kBounceCapRefr = 192;                   // refraction: RT_MAX_DEPTH + 2 x 64, see the pass sizing in the kernel
 template <int CAP>
 struct Queue {
   float* f;        // kQueueFields arrays of CAP words (field-major: conflict-free lane access)
@@ -855,13 +988,13 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // set b
   return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
 
-template <int MODE, bool REFR>
+template <int MODE, bool REFR, bool CUBES>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams p) {
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
   constexpr int kWaveLdsBytes = wave_lds_bytes(REFR);
   extern __shared__ __align__(16) unsigned char smem[];
-  float4* sg = reinterpret_cast<float4*>(smem);
-  const int geom_bytes = ((p.n_spheres * 16 + 15) / 16) * 16;
+  float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
+  const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
   float* s_cams = reinterpret_cast<float*>(smem + geom_bytes);                 // [kMaxBatch][12]
   uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_cams + kMaxBatch * 12);    // [kMaxBatch]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -870,6 +1003,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kCap * 4);
   int16_t* ring = reinterpret_cast<int16_t*>(pend + kPendingCap);               // [kRing][kVisTile] tile records
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
+  if constexpr (CUBES)
+    for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
   for (int i = tid; i < kMaxBatch * 12; i += kBlock) s_cams[i] = (&p.cams[0].origin[0])[i];
   if (tid < kMaxBatch) s_seeds[tid] = p.seeds[tid];
   __syncthreads();   // the only workgroup-wide synchronisation
@@ -1004,8 +1139,35 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
     // ------------------------------ shading pass -----------------------------------------
     {
       const unsigned long long s0 = RT_NOW();
-      const int nb = min(64, n_bounce), base = n_bounce - nb;       // bounce records: lanes [0, nb)
-      const int np = min(64 - nb, n_pend), base_p = n_pend - np;    // pending hits:   lanes [nb, nb + np)
+      int nb = min(64, n_bounce);                                   // bounce records: lanes [0, nb)
+      int np = min(64 - nb, n_pend);                                // pending hits:   lanes [nb, nb + np)
+      if constexpr (REFR) {
+        // A lane may push TWO records, so the queue can grow; it holds kCap records.  Records are taken
+        // from its top (deepest first) and a pass is sized from the levels found there: a record at
+        // max_depth pushes nothing, any other is counted as two pushes.  The pass takes the longest
+        // run of top records that either leaves no more than H = kCap - max_depth records behind, or
+        // contains at most one pushing record.  The second case is a depth-first walk below that
+        // record (one more record per level at most), which keeps every record's position below
+        // H + its level: the queue never holds more than H + max_depth = kCap records.  Pending hits
+        // (level 0) fill the lanes that are left while the first bound allows.
+        static_assert(kCap >= RT_MAX_DEPTH + 2 * 64, "a full pass of fresh hits must fit below the high-water mark");
+        const int high = kCap - p.max_depth;
+        int pushes = 0;
+        if (nb > 0) {
+          const bool mine = lane < nb;                               // lane l looks at the l-th record from the top
+          const uint32_t mt = mine ? __float_as_uint(q.at(13, n_bounce - 1 - lane)) : 0u;
+          const bool pushing = mine && int(mt & 255u) < p.max_depth;
+          const unsigned long long pm = __ballot(pushing);
+          const int upto = lanes_below(pm) + (pushing ? 1 : 0);      // pushing records among the top l + 1
+          const bool fits = mine && (n_bounce - (lane + 1) + 2 * upto <= high || upto <= 1);
+          const unsigned long long fm = __ballot(fits);              // bit 0 is always set
+          nb = 64 - __clzll((long long)fm);
+          pushes = __popcll(nb >= 64 ? pm : (pm & ((1ull << nb) - 1ull)));
+        }
+        const int after = n_bounce - nb + 2 * pushes;
+        np = min(min(64 - nb, n_pend), p.max_depth > 0 ? max(0, (high - after) / 2) : 64);
+      }
+      const int base = n_bounce - nb, base_p = n_pend - np;
       const bool have = lane < nb + np;
       // Lane l works on record slot e = base + l.  Only what the lighting loops need comes into
       // registers now (P, D, meta, key); T, acc and the pixel stay in the slot until after them.
@@ -1027,10 +1189,20 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         for (int k = 0; k < 12; ++k) (&cam.origin[0])[k] = s_cams[frame * 12 + k];
         // rebuild the primary ray and its hit point exactly as the visibility pass measured them
         primary_ray<MODE>(p, cam, s_seeds[frame], p.x0 + col, y, p.sample_index, pixel_key, dx, dy, dz);
-        const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-        float dl;
-        const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
-        px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
+        if (CUBES && idx >= p.n_spheres) {
+          float t = 0.f;
+          int face = 0;
+          const int c = idx - p.n_spheres;
+          cube_t(sg[p.n_spheres + 2 * c], sg[p.n_spheres + 2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2],
+                 dx, dy, dz, frcp(dx), frcp(dy), frcp(dz), t, face);
+          hit_point<CUBES>(sg, p.n_spheres, idx, face, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t,
+                           px, py, pz);                                                                        // :168
+        } else {
+          const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+          float dl;
+          const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
+          px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
+        }
         // meta: level (8 bits) | frame (8 bits) | sphere index (16 bits)
         meta = 0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16);
         // a fresh level-0 record: T = 1, acc = 0 (slots [base + nb, base + 64) are free)
@@ -1065,18 +1237,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         if (have) {
           const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
           ++n_shade;
-          const float4 s = sg[idx];
           const float4 m = p.mat[idx];
           const float spec = p.spec[idx];
           const float2 rf = p.refr[idx];
-          float nx = px - s.x, ny = py - s.y, nz = pz - s.z;               // :139-140
-          {
-            const float inv = frsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
-            nx *= inv; ny *= inv; nz *= inv;
-          }
+          float nx, ny, nz;
+          surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
           const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
           float lr, lg, lb;
-          lighting<MODE, 1, true>(p.L, sg, p.geom, p.refr, p.n_spheres, px, py, pz, nx, ny, nz, dx, dy, dz,
+          lighting<MODE, 1, true, CUBES>(p.L, sg, p.geom, p.refr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
                                   sx, sy, sz, m.x, m.y, m.z, spec, mix(pixel_key, uint32_t(level + 1)), lr, lg, lb);
           late_state();
           s2 = RT_NOW();
@@ -1091,12 +1259,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));
             rdx = fmaf(-dn2, nx, dx); rdy = fmaf(-dn2, ny, dy); rdz = fmaf(-dn2, nz, dz);
             float t;
-            int idx2;
+            int idx2, face;
             ++n_trace;
-            nearest_hit(sg, p.geom, p.n_spheres, sx, sy, sz, rdx, rdy, rdz, t, idx2);
+            nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
             if (idx2 >= 0) {
               push_r = true;
-              rpx = fmaf(rdx, t, sx); rpy = fmaf(rdy, t, sy); rpz = fmaf(rdz, t, sz);
+              hit_point<CUBES>(sg, p.n_spheres, idx2, face, sx, sy, sz, rdx, rdy, rdz, t, rpx, rpy, rpz);
               const float k = refl * (1.0f - refr);
               rtr = tr * k * lr; rtg = tg * k * lg; rtb = tb * k * lb;
               meta_r = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
@@ -1119,12 +1287,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
               fdx *= inv; fdy *= inv; fdz *= inv;
               const float ox = fmaf(qx, -0.001f, px), oy = fmaf(qy, -0.001f, py), oz = fmaf(qz, -0.001f, pz);  // :229
               float t;
-              int idx2;
+              int idx2, face;
               ++n_trace;
-              nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, fdx, fdy, fdz, t, idx2);
+              nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
               if (idx2 >= 0) {
                 push_f = true;
-                fpx = fmaf(fdx, t, ox); fpy = fmaf(fdy, t, oy); fpz = fmaf(fdz, t, oz);
+                hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, fdx, fdy, fdz, t, fpx, fpy, fpz);
                 ftr = tr * refr * lr; ftg = tg * refr * lg; ftb = tb * refr * lb;
                 meta_f = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
               }
@@ -1133,7 +1301,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         }
         wave_lds_fence();   // every lane has its whole record in registers before slots are rewritten
         const unsigned long long mask_r = __ballot(push_r), mask_f = __ballot(push_f);
-        if (push_r) {
+        // (slot < kCap always holds by the pass sizing above; the test only keeps a logic error from
+        // becoming a stray LDS write)
+        if (push_r && base + lanes_below(mask_r) < kCap) {
           const int slot = base + lanes_below(mask_r);
           q.at(0, slot) = rpx; q.at(1, slot) = rpy; q.at(2, slot) = rpz;
           q.at(3, slot) = rdx; q.at(4, slot) = rdy; q.at(5, slot) = rdz;
@@ -1142,7 +1312,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           q.at(13, slot) = __uint_as_float(meta_r);
           q.at(14, slot) = __uint_as_float(pixel_key);
         }
-        if (push_f) {
+        if (push_f && base + __popcll(mask_r) + lanes_below(mask_f) < kCap) {
           const int slot = base + __popcll(mask_r) + lanes_below(mask_f);
           q.at(0, slot) = fpx; q.at(1, slot) = fpy; q.at(2, slot) = fpz;
           q.at(3, slot) = fdx; q.at(4, slot) = fdy; q.at(5, slot) = fdz;
@@ -1151,7 +1321,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           q.at(13, slot) = __uint_as_float(meta_f);
           q.at(14, slot) = __uint_as_float(pixel_key);
         }
-        n_bounce = base + __popcll(mask_r) + __popcll(mask_f);
+        n_bounce = min(kCap, base + __popcll(mask_r) + __popcll(mask_f));
         wave_lds_fence();
         const unsigned long long s3 = RT_NOW();
         st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
@@ -1162,18 +1332,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         ++n_shade;
         float ox, oy, oz;
         const uint32_t level_key = mix(pixel_key, uint32_t(level + 1));
-        bool cont = shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, level_key,
-                                    tr, tg, tb, ar, ag, ab, ox, oy, oz, late_state);
+        bool cont = shade_hit<MODE, CUBES>(p, sg, idx, px, py, pz, dx, dy, dz, level_key,
+                                           tr, tg, tb, ar, ag, ab, ox, oy, oz, late_state);
         cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
         s2 = RT_NOW();
         if (cont) {
           float t;
-          int idx2;
+          int idx2, face;
           ++n_trace;
-          nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);
+          nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, dx, dy, dz, t, idx2, face);
           if (idx2 >= 0) {
             again = true;
-            px = fmaf(dx, t, ox); py = fmaf(dy, t, oy); pz = fmaf(dz, t, oz);
+            hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, dx, dy, dz, t, px, py, pz);
             meta = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
           }
         }
@@ -1350,8 +1520,11 @@ struct rt_ctx {
   float4* d_geom = nullptr;
   float4* d_mat = nullptr;
   float* d_spec = nullptr;
-  float2* d_refr = nullptr;      // refraction, refractive_index per sphere (rt_set_refraction)
+  float2* d_refr = nullptr;      // refraction, refractive_index per object (rt_set_refraction, rt_set_cubes)
   bool has_refr = false;         // some sphere has refraction > 0: the REFR kernels run
+  bool has_refr_cubes = false;   // some cube has
+  float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
+  int n_cubes = 0;
   unsigned long long* d_counters = nullptr;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
@@ -1406,6 +1579,21 @@ struct Window {
   int x0, nx, n_rows, tile_rows, tile_first, tile_stride, y0;
 };
 
+// kernel variants: RNG mode x refraction in the scene x cubes in the scene
+using RenderKernel = void (*)(const RenderParams);
+RenderKernel pick_visibility_kernel(int rng_mode, bool cubes) {
+  if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true> : rt_visibility_kernel<RT_RNG_KEYED, false>;
+  return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false>;
+}
+RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes) {
+  if (rng_mode == RT_RNG_KEYED) {
+    if (refr) return cubes ? rt_stream_kernel<RT_RNG_KEYED, true, true> : rt_stream_kernel<RT_RNG_KEYED, true, false>;
+    return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true> : rt_stream_kernel<RT_RNG_KEYED, false, false>;
+  }
+  if (refr) return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, true, true> : rt_stream_kernel<RT_RNG_CONSTANT, true, false>;
+  return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true> : rt_stream_kernel<RT_RNG_CONSTANT, false, false>;
+}
+
 // Validates, then launches ceil(n_frames / 16) x samples kernels on ctx->stream.
 int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames, int width,
            int height, const Window& w, int samples, int max_depth, int rng_mode, uint8_t* out_rgb,
@@ -1436,9 +1624,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   RT_HIP(ctx, hipSetDevice(ctx->device));
   const int batch = std::min(n_frames, kMaxBatch);
-  const bool refr = ctx->has_refr;
-  if (refr && ctx->kernel != RT_KERNEL_STREAM)
-    return fail(ctx, RT_ESTATE, "refractive materials need the default kernel (RT_KERNEL_STREAM)");
+  const bool refr = ctx->has_refr || ctx->has_refr_cubes;
+  const bool cubes = ctx->n_cubes > 0;
+  if ((refr || cubes) && ctx->kernel != RT_KERNEL_STREAM)
+    return fail(ctx, RT_ESTATE, "refractive materials and cubes need the default kernel (RT_KERNEL_STREAM)");
   if (samples > 1 || refr) {  // running sums over samples (and tree nodes), one slab per frame of a batch
     const size_t need = size_t(win_px) * 3 * size_t(batch);
     if (need > ctx->accum_floats) {
@@ -1473,6 +1662,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.inv_samples = 1.0f / float(samples);
   p.n_spheres = ctx->n_spheres;
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
+  p.cubes = ctx->d_cubes; p.n_cubes = ctx->n_cubes;
   p.defer_output = refr ? 1 : 0;
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
@@ -1490,7 +1680,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   } else {
     per_frame = unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH);
   }
-  const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres, refr) : pixel_lds(ctx->n_spheres);
+  const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr) : pixel_lds(ctx->n_spheres);
 
   for (int f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
     const int nf = std::min(kMaxBatch, n_frames - f0);
@@ -1528,15 +1718,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, kTileCounters * 128, ctx->stream));
-        if (rng_mode == RT_RNG_KEYED) {
-          hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_KEYED>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
-          if (refr) hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_KEYED, true>), sgrid, dim3(kBlock), lds, ctx->stream, p);
-          else hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_KEYED, false>), sgrid, dim3(kBlock), lds, ctx->stream, p);
-        } else {
-          hipLaunchKernelGGL(rt_visibility_kernel<RT_RNG_CONSTANT>, vgrid, dim3(kBlock), vlds, ctx->stream, p);
-          if (refr) hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_CONSTANT, true>), sgrid, dim3(kBlock), lds, ctx->stream, p);
-          else hipLaunchKernelGGL((rt_stream_kernel<RT_RNG_CONSTANT, false>), sgrid, dim3(kBlock), lds, ctx->stream, p);
-        }
+        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes), vgrid, dim3(kBlock), vlds, ctx->stream, p);
+        hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples)
           hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
                              ctx->stream, p);
@@ -1597,6 +1780,7 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_mat, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_refr, sizeof(float2) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_chunk, kTileCounters * 128)) != hipSuccess) return bail(e, "hipMalloc");
@@ -1606,11 +1790,12 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMemset");
   const size_t big = stream_lds(RT_MAX_SPHERES), bigr = stream_lds(RT_MAX_SPHERES, true);
-  if ((e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED, false>, big)) != hipSuccess ||
-      (e = allow_big_lds(rt_stream_kernel<RT_RNG_CONSTANT, false>, big)) != hipSuccess ||
-      (e = allow_big_lds(rt_stream_kernel<RT_RNG_KEYED, true>, bigr)) != hipSuccess ||
-      (e = allow_big_lds(rt_stream_kernel<RT_RNG_CONSTANT, true>, bigr)) != hipSuccess ||
-      (e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
+  for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c)
+        if ((e = allow_big_lds(pick_stream_kernel(mode, r != 0, c != 0), r ? bigr : big)) != hipSuccess)
+          return bail(e, "hipFuncSetAttribute");
+  if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
       (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
   *out = ctx;
@@ -1625,6 +1810,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_mat) (void)hipFree(ctx->d_mat);
   if (ctx->d_spec) (void)hipFree(ctx->d_spec);
   if (ctx->d_refr) (void)hipFree(ctx->d_refr);
+  if (ctx->d_cubes) (void)hipFree(ctx->d_cubes);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -1684,6 +1870,9 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     RT_HIP(ctx, hipMemcpy(ctx->d_geom, geom4, sizeof(float) * 4 * n_spheres, hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_mat, mat4, sizeof(float) * 4 * n_spheres, hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_spec, spec, sizeof(float) * n_spheres, hipMemcpyHostToDevice));
+    // Material's defaults (raytracer.py:43): refraction 0, refractive_index 1 (read when a cube is refractive)
+    const std::vector<float2> defaults(size_t(n_spheres), make_float2(0.0f, 1.0f));
+    RT_HIP(ctx, hipMemcpy(ctx->d_refr, defaults.data(), sizeof(float2) * size_t(n_spheres), hipMemcpyHostToDevice));
   }
   DevLights& L = ctx->lights;
   memcpy(L.ppos, lights->point_pos, 12); memcpy(L.pcol, lights->point_color, 12);
@@ -1695,6 +1884,47 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
                    std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
   ctx->n_spheres = n_spheres;
   ctx->has_refr = false;   // Material's defaults (raytracer.py:43) until rt_set_refraction says otherwise
+  ctx->n_cubes = 0;        // the object list holds spheres only until rt_set_cubes says otherwise
+  ctx->has_refr_cubes = false;
+  return RT_OK;
+}
+
+int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float* spec, const float* refraction,
+                 const float* refractive_index, int n_cubes) {
+  if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
+  if (ctx->n_spheres < 0) return fail(ctx, RT_ESTATE, "rt_upload_scene has not been called");
+  if (n_cubes < 0 || ctx->n_spheres + 2 * n_cubes > RT_MAX_SPHERES)
+    return fail(ctx, RT_EINVAL, "n_cubes %d out of range: n_spheres + 2 n_cubes must not exceed %d", n_cubes,
+                RT_MAX_SPHERES);
+  if (n_cubes > 0 && (!box6 || !mat4 || !spec)) return fail(ctx, RT_EINVAL, "cube array is NULL");
+  std::vector<float4> box(size_t(2 * std::max(n_cubes, 1)));
+  std::vector<float2> rf(size_t(std::max(n_cubes, 1)));
+  bool any = false;
+  for (int i = 0; i < n_cubes; ++i) {
+    for (int k = 0; k < 6; ++k)
+      if (!std::isfinite(box6[6 * i + k])) return fail(ctx, RT_EINVAL, "cube %d has a non-finite corner", i);
+    for (int k = 0; k < 4; ++k)
+      if (!std::isfinite(mat4[4 * i + k])) return fail(ctx, RT_EINVAL, "cube %d has a non-finite material", i);
+    if (!std::isfinite(spec[i])) return fail(ctx, RT_EINVAL, "cube %d has a non-finite specular", i);
+    const float f = refraction ? refraction[i] : 0.0f, ri = refractive_index ? refractive_index[i] : 1.0f;
+    if (!std::isfinite(f) || !std::isfinite(ri)) return fail(ctx, RT_EINVAL, "cube %d: non-finite refraction value", i);
+    if (f > 0.0f && !(ri > 0.0f)) return fail(ctx, RT_EINVAL, "cube %d: refractive_index must be > 0", i);
+    box[size_t(2 * i)] = make_float4(box6[6 * i], box6[6 * i + 1], box6[6 * i + 2], 0.0f);
+    box[size_t(2 * i + 1)] = make_float4(box6[6 * i + 3], box6[6 * i + 4], box6[6 * i + 5], 0.0f);
+    rf[size_t(i)] = make_float2(f, ri);
+    any = any || f > 0.0f;
+  }
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_cubes > 0) {
+    const size_t at = size_t(ctx->n_spheres);   // cubes are objects n_spheres, n_spheres + 1, ...
+    RT_HIP(ctx, hipMemcpy(ctx->d_cubes, box.data(), sizeof(float4) * 2 * size_t(n_cubes), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_mat + at, mat4, sizeof(float4) * size_t(n_cubes), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_spec + at, spec, sizeof(float) * size_t(n_cubes), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_refr + at, rf.data(), sizeof(float2) * size_t(n_cubes), hipMemcpyHostToDevice));
+  }
+  ctx->n_cubes = n_cubes;
+  ctx->has_refr_cubes = any;
   return RT_OK;
 }
 

@@ -80,6 +80,10 @@ class Renderer:
             f = np.ascontiguousarray(p.refr[:, 0], np.float32)
             ri = np.ascontiguousarray(p.refr[:, 1], np.float32)
             self._check(self._L.rt_set_refraction(self._h, f.ctypes.data, ri.ctypes.data, p.n_spheres))
+        if p.n_cubes:             # Cube members of the object list (raytracer.py:56-60, :157-160)
+            a = [np.ascontiguousarray(x, np.float32) for x in
+                 (p.cube_box, p.cube_mat4, p.cube_spec, p.cube_refr[:, 0], p.cube_refr[:, 1])]
+            self._check(self._L.rt_set_cubes(self._h, *[x.ctypes.data for x in a], p.n_cubes))
         self._packed = p
         return p
 
@@ -102,6 +106,11 @@ class Renderer:
             self._check(self._L.rt_render(self._h, ctypes.byref(cam), width, height, int(samples),
                                           int(max_depth), _lib.RNG_MODES[rng_mode], int(seed),
                                           out.data_ptr(), hit.data_ptr() if hit is not None else None))
+        p = self._packed
+        if hit is not None and p is not None and not np.array_equal(p.order, np.arange(len(p.order))):
+            # device index (spheres, then cubes) -> position in the scene's object list
+            table = torch.tensor(list(p.order) + [-1], dtype=torch.int32, device=hit.device)
+            hit = table[hit.long()]
         return (out, hit) if return_hit_index else out
 
     def render_rows(self, width, height, samples=1, *, tile_rows, tile_first, tile_stride,

@@ -39,7 +39,8 @@ def scene_dict_from_arrays(a):
     from raytracer_amd.scenes import scene_from_arrays
     return scene_from_arrays(a["center"], a["radius"], a["color"], a["specular"], a["reflection"],
                              a["lights"], int(a["area_samples"]), refraction=a.get("refraction"),
-                             refractive_index=a.get("refractive_index"))
+                             refractive_index=a.get("refractive_index"), kind=a.get("kind"),
+                             box_max=a.get("box_max"))
 
 
 @pytest.fixture(scope="session")

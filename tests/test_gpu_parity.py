@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_scene_arrays, load_golden, scene_dict_from_arrays
-from raytracer_amd.scenes import (Camera, Material, Sphere, Vector3, default_scene,
+from raytracer_amd.scenes import (Camera, Cube, Material, Sphere, Vector3, cube_scene, default_scene,
                                   generate_scene, orbit_camera, pack_scene, refractive_scene)
 
 pytestmark = pytest.mark.gpu
@@ -239,6 +239,95 @@ def test_refraction_glass_in_front_of_light_does_not_shadow(renderer, oracle):
         check_rgb(img, o["rgb8"])
         imgs.append(img.astype(int))
     assert (imgs[0].sum(-1) > imgs[1].sum(-1) + 30).mean() > 0.01   # the opaque sphere's shadow is gone
+
+
+def check_cube_hits(gpu_hit, o):
+    """Primary hit index with cubes in the list: the oracle's margin only knows sphere silhouettes, so
+    mismatches are bounded in number (edges of a box are one pixel wide) instead of classified."""
+    bad = np.asarray(gpu_hit).ravel() != np.asarray(o["hit"]).ravel()
+    assert bad.mean() <= 5e-4, f"{bad.sum()} hit-index mismatches of {bad.size}"
+
+
+@pytest.mark.parametrize("name", ["cube_opaque_200x150_D5_spp2_modeK", "cube_glass_200x150_D3_spp1_modeC",
+                                  "cube_glass_200x150_D5_spp1_modeK"])
+def test_cubes_against_reference_goldens(renderer, name):
+    """SURVEY.md 8(f) rank 3.  The cube fixtures come from the reference itself (oracle/gen_golden.py):
+    Cube objects first, in the middle and last in scene['spheres']."""
+    g = load_golden(name)
+    m = g["meta"]
+    renderer.upload_scene(scene_dict_from_arrays(golden_scene_arrays(g)))
+    img, hit = renderer.render(m["width"], m["height"], m["samples"], max_depth=m["max_depth"], rng_mode=m["mode"],
+                               seed=m["seed"], return_hit_index=True)
+    check_rgb(img.cpu().numpy(), g["rgb8"])
+    check_cube_hits(hit.cpu().numpy(), dict(hit=g["hit"]))       # list positions, not device indices
+
+
+@pytest.mark.parametrize("glass,w,h,D,spp,mode", [(False, 320, 240, 5, 1, "K"), (False, 333, 187, 5, 2, "K"),
+                                                  (True, 320, 240, 5, 1, "K"), (True, 160, 120, 2, 1, "C"),
+                                                  (False, 1920, 1080, 5, 1, "K")])
+def test_cubes_against_oracle(renderer, oracle, glass, w, h, D, spp, mode):
+    """intersect_cube / cube_normal (raytracer.py:106-150) in every scan of the path: primary rays
+    (visibility pass), reflection and refraction rays, shadow rays (any-hit in the opaque scene,
+    nearest-hit in the glass scene), up to BASELINE's 1080p."""
+    scene = cube_scene(glass)
+    renderer.upload_scene(scene)
+    renderer.reset_ray_counts()
+    img, hit = renderer.render(w, h, spp, max_depth=D, rng_mode=mode, seed=4, return_hit_index=True)
+    o = oracle.render_scene(scene, w, h, samples=spp, max_depth=D, mode=mode, seed=4)
+    check_cube_hits(hit.cpu().numpy(), o)
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+    rc = renderer.ray_counts()
+    assert rc["primary"] == w * h * spp and rc["shadow"] == 13 * rc["shaded_hits"]
+    assert abs(rc["shaded_hits"] - int(o["hit_levels"].sum())) <= max(8, 2e-3 * o["hit_levels"].sum())
+    assert abs(rc["primary"] + rc["reflection"] - int(o["trace_levels"].sum())) \
+        <= max(8, 2e-3 * o["trace_levels"].sum())
+    if w <= 400:
+        c = renderer.render_chunk(10, 150, 20, 110, w, h, spp, max_depth=D, rng_mode=mode, seed=4).cpu().numpy()
+        ref = np.clip(o["color"].reshape(h, w, 3)[20:110, 10:150], 0, 1)
+        assert (np.abs(c - ref).max(-1) < 1e-3).mean() >= PIXEL_FRACTION
+        # a later sphere-only scene on the same context: the cubes are gone
+        renderer.upload_scene(default_scene())
+        img2 = renderer.render(w, h, 1, max_depth=D, rng_mode=mode, seed=4)
+        o2 = oracle.render_scene(default_scene(), w, h, samples=1, max_depth=D, mode=mode, seed=4)
+        check_rgb(img2.cpu().numpy(), o2["rgb8"])
+
+
+def test_every_hit_branches_bounded_queue(renderer, oracle):
+    """Inside a glass box that also reflects, every hit has two children down to the depth limit (the box
+    is hit by every ray, :137): 2^(D+1) - 1 shaded hits per pixel.  The stream kernel's bounce queue is
+    a fixed LDS array; its pass sizing must keep that tree inside it for any depth."""
+    m = Material(Vector3(0.9, 0.8, 1.0), specular=0.3, reflection=0.4, refraction=0.5, refractive_index=1.0)
+    sc = _scene([Cube(Vector3(-4, -3, -8), Vector3(4, 3, 2), m), default_scene()["spheres"][0]])
+    for w, h, D in ((96, 64, 7), (64, 40, 9), (200, 150, 3)):
+        renderer.upload_scene(sc)
+        renderer.reset_ray_counts()
+        img, hit = renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=2, return_hit_index=True)
+        o = oracle.render_scene(sc, w, h, max_depth=D, mode="K", seed=2)
+        assert (o["hit_levels"] == 2 ** (D + 1) - 1).mean() > 0.8
+        check_cube_hits(hit.cpu().numpy(), o)
+        check_rgb(img.cpu().numpy(), o["rgb8"])
+        rc = renderer.ray_counts()
+        assert abs(rc["shaded_hits"] - int(o["hit_levels"].sum())) <= 2e-3 * o["hit_levels"].sum()
+
+
+def test_cube_edge_cases(renderer, oracle):
+    """Camera inside a box (t_min < 0 -> t_max, :137), a box behind the camera (t < 0 accepted by :162 and
+    beating every sphere), rays parallel to slabs (|d| < 1e-8, :124-126: centre column / row of an
+    odd-sized frame), a box as the only object, and cube_normal's face order on a box seen edge-on."""
+    m = Material(Vector3(0.9, 0.7, 0.5), specular=0.5, reflection=0.3, refraction=0.5, refractive_index=1.3)
+    mo = Material(Vector3(0.9, 0.7, 0.5), specular=0.5, reflection=0.3)
+    d = default_scene()["spheres"]
+    cases = [[d[1], Cube(Vector3(-3, -2, -9), Vector3(3, 2, 1), m), d[2]],
+             [d[1], Cube(Vector3(-0.5, -0.5, 2), Vector3(0.5, 0.5, 3), mo), d[2]],
+             [d[0], Cube(Vector3(-0.5, -0.5, 2), Vector3(0.5, 0.5, 3), m), d[2]],
+             [Cube(Vector3(-1, -1, -6), Vector3(1, 1, -4), m)],
+             [d[1], d[2], Cube(Vector3(-1, -1, -6), Vector3(1, 1, -4), m), Cube(Vector3(0.5, 0.2, -3.5), Vector3(1.5, 1.2, -3), m)]]
+    for objs in cases:
+        sc = _scene(objs)
+        img, hit, o = _both(renderer, oracle, sc, w=161, h=91, D=4, mode="K")
+        check_cube_hits(hit, o)
+        check_rgb(img, o["rgb8"])
+        assert (o["hit"] == [isinstance(x, Cube) for x in objs].index(True)).any()
 
 
 # ---- hand-made edge scenes (same as tests/test_oracle_semantics.py) --------------------------

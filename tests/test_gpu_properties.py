@@ -174,6 +174,53 @@ def test_refraction_abi(renderer):
     assert not np.array_equal(a, b)
 
 
+def test_cubes_abi(renderer):
+    """rt_set_cubes: argument checks, reset by rt_upload_scene, RT_KERNEL_PIXEL refused, hit indices
+    reported as positions in the scene's object list, batches and row tiles agree with single frames."""
+    import torch
+    from raytracer_amd import tiling
+    from raytracer_amd.scenes import cube_scene
+    L = _lib.load()
+    pk = renderer.upload_scene(cube_scene(True))
+    assert pk.n_cubes == 3 and list(pk.order) == [1, 2, 4, 0, 3, 5]
+    box, mat, spec = (np.ascontiguousarray(a) for a in (pk.cube_box, pk.cube_mat4, pk.cube_spec))
+    f = np.ascontiguousarray(pk.cube_refr[:, 0]); ri = np.ascontiguousarray(pk.cube_refr[:, 1])
+    h = renderer._h
+    assert L.rt_set_cubes(h, box.ctypes.data, mat.ctypes.data, spec.ctypes.data, f.ctypes.data, ri.ctypes.data, -1) == -1
+    assert L.rt_set_cubes(h, box.ctypes.data, mat.ctypes.data, spec.ctypes.data, f.ctypes.data, ri.ctypes.data, 1100) == -1
+    assert L.rt_set_cubes(h, None, mat.ctypes.data, spec.ctypes.data, None, None, 3) == -1
+    bad = box.copy(); bad[1, 2] = np.inf
+    assert L.rt_set_cubes(h, bad.ctypes.data, mat.ctypes.data, spec.ctypes.data, None, None, 3) == -1
+    assert b"cube 1" in L.rt_last_error(h)
+    badri = ri.copy(); badri[0] = -1.0
+    assert L.rt_set_cubes(h, box.ctypes.data, mat.ctypes.data, spec.ctypes.data, f.ctypes.data, badri.ctypes.data, 3) == -1
+    assert L.rt_set_cubes(h, box.ctypes.data, mat.ctypes.data, spec.ctypes.data, f.ctypes.data, ri.ctypes.data, 3) == 0
+    renderer.set_kernel("pixel")
+    try:
+        with pytest.raises(_lib.RtError):
+            renderer.render(64, 48, 1)
+    finally:
+        renderer.set_kernel("stream")
+    a, hit = renderer.render(200, 120, 1, rng_mode="K", seed=3, return_hit_index=True)
+    assert set(np.unique(hit.cpu().numpy())) == {-1, 0, 1, 2, 4, 5}     # list positions; cube 3 is out of view
+    # opaque cubes (NULL refraction arrays = Material's defaults): the fast any-hit path; batches and tiles
+    assert L.rt_set_cubes(h, box.ctypes.data, mat.ctypes.data, spec.ctypes.data, None, None, 3) == 0
+    one = renderer.render(200, 120, 1, rng_mode="K", seed=3)
+    assert not torch.equal(one, a)
+    cams = [None, orbit_camera(3, 64), None]
+    batch = renderer.render_frames(cams, [3, 9, 3], 200, 120, 1, rng_mode="K")
+    assert torch.equal(batch[0], one) and torch.equal(batch[2], one) and not torch.equal(batch[1], one)
+    rows = renderer.render_rows(200, 120, 1, tile_rows=8, tile_first=1, tile_stride=2, rng_mode="K", seed=3)
+    assert torch.equal(rows, one[torch.as_tensor(tiling.local_rows(120, 8, 1, 2), device=one.device)])
+    renderer.upload_scene(default_scene())          # the object list holds spheres only again
+    renderer.set_kernel("pixel")
+    try:
+        b = renderer.render(200, 120, 1, rng_mode="K", seed=3)
+    finally:
+        renderer.set_kernel("stream")
+    assert torch.equal(b, renderer.render(200, 120, 1, rng_mode="K", seed=3)) and not torch.equal(b, one)
+
+
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
     pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""

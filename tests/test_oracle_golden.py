@@ -23,12 +23,13 @@ def _run(oracle, g, pixels=None, **over):
     return oracle.render_pixels(a["center"], a["radius"], a["color"], a["specular"], a["reflection"],
                                 a["lights"], int(a["area_samples"]), m["width"], m["height"],
                                 pixels=pixels, refraction=a.get("refraction"),
-                                refractive_index=a.get("refractive_index"), **kw)
+                                refractive_index=a.get("refractive_index"), kind=a.get("kind"),
+                                box_max=a.get("box_max"), **kw)
 
 
 def test_all_fixtures_are_covered():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    known = set(SPARSE + PIN + REFR + ["c5_orbit_1920x1080_D5", "c1_default_640x480_D3_modeC",
+    known = set(SPARSE + PIN + REFR + CUBE + ["c5_orbit_1920x1080_D5", "c1_default_640x480_D3_modeC",
                                        "c1_default_640x480_D3_modeK"])
     assert set(names) == known
 
@@ -63,6 +64,33 @@ def test_refraction_full_frames_bit_exact(oracle, name):
     assert np.array_equal(o["hit_levels"].reshape(h, w), g["hit_levels"])
     # a refractive hit has two children: more levels per sample than the D + 1 of a chain
     assert g["trace_levels"].max() > g["meta"]["samples"] * (g["meta"]["max_depth"] + 1)
+
+
+CUBE = ["cube_opaque_200x150_D5_spp2_modeK", "cube_glass_200x150_D3_spp1_modeC", "cube_glass_200x150_D5_spp1_modeK"]
+
+
+@pytest.mark.parametrize("name", CUBE)
+def test_cube_full_frames_bit_exact(oracle, name):
+    """intersect_cube / cube_normal (raytracer.py:106-150) through find_nearest_intersection's type
+    dispatch (:157-169), from the reference run on raytracer_amd.scenes.cube_scene()."""
+    g = load_golden(name)
+    h, w = g["meta"]["height"], g["meta"]["width"]
+    a = golden_scene_arrays(g)
+    assert list(a["kind"]) == [1, 0, 0, 1, 0, 1]           # cubes first, in the middle and last in the list
+    o = _run(oracle, g)
+    assert np.array_equal(o["color"].reshape(h, w, 3), g["color"])
+    assert np.array_equal(o["rgb8"].reshape(h, w, 3), g["rgb8"])
+    assert np.array_equal(o["hit"].reshape(h, w), g["hit"])
+    assert np.array_equal(o["trace_levels"].reshape(h, w), g["trace_levels"])
+    assert np.array_equal(o["hit_levels"].reshape(h, w), g["hit_levels"])
+    hit = g["hit"]
+    assert (hit == 0).sum() > 100 and (hit == 5).sum() > 50      # cubes are seen directly
+    lit = g["color"].sum(-1) > 0
+    if "opaque" in name:    # an opaque cube shadows itself through the t < 0 rule (:137, :162)
+        assert lit[hit == 0].mean() < 0.05
+    else:                   # glass: its own nearest (t < 0) hit is refractive, so it stays lit (:187)
+        assert lit[hit == 0].mean() > 0.95
+    assert 0.5 < lit[(hit == 1) | (hit == 2) | (hit == 4)].mean() < 0.995   # the cubes' line shadows on the spheres
 
 
 @pytest.mark.parametrize("name", PIN)
