@@ -366,35 +366,49 @@ __device__ __forceinline__ camtab_t as_const(const CamGroup* p) { return p; }
 __host__ __device__ __forceinline__ int cam_groups_scanned(int n) { return (((n + 3) >> 2) + 1) & ~1; }
 __host__ __device__ __forceinline__ int cam_groups_stride(int n) { return cam_groups_scanned(n) + 1; }
 
-__device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
-                                            int n, float ox, float oy, float oz, float dx, float dy,
-                                            float dz, float& best_t, int& best_i) {
-  best_t = INFINITY;
-  best_i = -1;
+// NP rays per lane against the same table entries: the scalar loads, the loop and the candidate
+// branch are shared (the visibility pass traces two pixels per lane: it is issue-bound, and scalar
+// instructions are ~40 % of what a one-pixel wave issues).
+template <int NP>
+__device__ __forceinline__ void primary_hit_n(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
+                                              int n, float ox, float oy, float oz, const float (&dx)[NP],
+                                              const float (&dy)[NP], const float (&dz)[NP], float (&best_t)[NP],
+                                              int (&best_i)[NP]) {
+  float inv_a[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    best_t[q] = INFINITY;
+    best_i[q] = -1;
+    inv_a[q] = frcp(fmaf(dz[q], dz[q], fmaf(dy[q], dy[q], dx[q] * dx[q])));
+  }
   const int ngroups = cam_groups_scanned(n);   // padded with never-hit entries
   camtab_t tab = as_const(camtab);
   cgeom_t geom = as_const(gg);   // candidates are rare: their sphere comes by scalar load
-  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
   auto test_group = [&](const CamGroup& grp, int g) {
-    float nb[4], disc[4];
+    float nb[NP][4], disc[NP][4];
     uint32_t any = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      nb[j] = fmaf(grp.z[j], dz, fmaf(grp.y[j], dy, grp.x[j] * dx));
-      disc[j] = fmaf(nb[j], nb[j], grp.negc[j]);
-      any &= __float_as_uint(disc[j]) | __float_as_uint(nb[j]);
-    }
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        nb[q][j] = fmaf(grp.z[j], dz[q], fmaf(grp.y[j], dy[q], grp.x[j] * dx[q]));
+        disc[q][j] = fmaf(nb[q][j], nb[q][j], grp.negc[j]);
+        any &= __float_as_uint(disc[q][j]) | __float_as_uint(nb[q][j]);
+      }
     if (int(any) >= 0) {
       // some lane may hit one of these four spheres: decide and measure with the cancellation-free
       // form of nearest_hit (the table's c carries a safety margin, so this is a superset)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (disc[j] >= 0.0f && nb[j] > 0.0f) {
-          float dl;
-          const float t = sphere_t_exact(geom[4 * g + j], ox, oy, oz, dx, dy, dz, inv_a, dl);
-          if (dl >= 0.0f && t > 0.0f && t < best_t) {
-            best_t = t;
-            best_i = 4 * g + j;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          if (disc[q][j] >= 0.0f && nb[q][j] > 0.0f) {
+            float dl;
+            const float t = sphere_t_exact(geom[4 * g + j], ox, oy, oz, dx[q], dy[q], dz[q], inv_a[q], dl);
+            if (dl >= 0.0f && t > 0.0f && t < best_t[q]) {
+              best_t[q] = t;
+              best_i[q] = 4 * g + j;
+            }
           }
         }
       }
@@ -409,6 +423,16 @@ __device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const
     a = tab[g + 2];
     test_group(b, g + 1);
   }
+}
+__device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
+                                            int n, float ox, float oy, float oz, float dx, float dy,
+                                            float dz, float& best_t, int& best_i) {
+  const float ax[1] = {dx}, ay[1] = {dy}, az[1] = {dz};
+  float t[1];
+  int i[1];
+  primary_hit_n<1>(gg, camtab, n, ox, oy, oz, ax, ay, az, t, i);
+  best_t = t[0];
+  best_i = i[0];
 }
 
 // Per-frame table for primary_hit (one tiny launch per batch, ahead of the render kernel on the
@@ -848,68 +872,90 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
 // ------------------------------------------------------------------------------------------
 template <int MODE, bool CUBES>
 __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderParams p) {
+  // a wave covers two 8x8 tiles side by side: lane (lx, ly) traces pixel (lx, ly) of both
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * 4 + wave) * 8, row0 = int(blockIdx.x) * 8;   // window coordinates
+  const int col0 = (int(blockIdx.y) * 4 + wave) * 16, row0 = int(blockIdx.x) * 8;   // window coordinates
   const int lx = lane & 7, ly = lane >> 3;
-  const int cols = min(8, p.nx - col0), rows = min(8, p.n_rows - row0);
-  if (cols <= 0) return;                                  // wave-uniform: tile beyond the right edge
+  const int rows = min(8, p.n_rows - row0);
+  const int cols[2] = {min(8, p.nx - col0), min(8, p.nx - col0 - 8)};
+  if (cols[0] <= 0) return;                               // wave-uniform: both tiles beyond the right edge
   const long long frame_px = (long long)frame * p.frame_stride_px;
   const long long accum_px = (long long)frame * p.accum_stride_px;
   const bool last_sample = p.sample_index + 1 == p.n_samples;
-  const bool live = lx < cols && ly < rows;
-  const long long wpix = (long long)(row0 + ly) * p.nx + (col0 + lx);
-  int idx = -1;
-  uint32_t rgbx = 0u;                                     // hit pixels: placeholder
-  if (live) {
+  const bool live[2] = {lx < cols[0] && ly < rows, lx < cols[1] && ly < rows};
+  const long long wpix0 = (long long)(row0 + ly) * p.nx + (col0 + lx);      // second pixel: + 8
+  int idx[2] = {-1, -1};
+  uint32_t rgbx[2] = {0u, 0u};                            // hit pixels: placeholder
+  if (live[0]) {                                          // (live[1] implies live[0])
     const rt_camera& cam = p.cams[frame];
     const int y = tile_rows_uniform(p) ? tile_row_base(p, row0) + ly : row_of(p, row0 + ly);
-    uint32_t pixel_key;
-    float dx, dy, dz, t;
-    primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + lx, y, p.sample_index, pixel_key, dx, dy, dz);
-    primary_hit(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
-                cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+    float dx[2], dy[2], dz[2], t[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      uint32_t pixel_key;
+      primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + 8 * q + lx, y, p.sample_index, pixel_key, dx[q], dy[q],
+                        dz[q]);
+    }
+    primary_hit_n<2>(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
+                     cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
       cgeom_t cg = as_const(p.cubes);
-      const float ix = frcp(dx), iy = frcp(dy), iz = frcp(dz);
+      float ix[2], iy[2], iz[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { ix[q] = frcp(dx[q]); iy[q] = frcp(dy[q]); iz[q] = frcp(dz[q]); }
       for (int c = 0; c < p.n_cubes; ++c) {
-        float tc;
-        int face;
-        if (cube_t(cg[2 * c], cg[2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, ix, iy, iz,
-                   tc, face) && tc < t) {
-          t = tc; idx = p.n_spheres + c;
+        const float4 lo = cg[2 * c], hi = cg[2 * c + 1];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float tc;
+          int face;
+          if (cube_t(lo, hi, cam.origin[0], cam.origin[1], cam.origin[2], dx[q], dy[q], dz[q], ix[q], iy[q], iz[q],
+                     tc, face) && tc < t[q]) {
+            t[q] = tc; idx[q] = p.n_spheres + c;
+          }
         }
       }
     }
-    if (p.out_hit && last_sample) p.out_hit[frame_px + wpix] = idx;
-    if (idx < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
-      finish_pixel(p, frame_px + wpix, accum_px + wpix, 0.f, 0.f, 0.f, &rgbx);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!live[q]) idx[q] = -1;
+      if (live[q] && p.out_hit && last_sample) p.out_hit[frame_px + wpix0 + 8 * q] = idx[q];
+      if (live[q] && idx[q] < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
+        finish_pixel(p, frame_px + wpix0 + 8 * q, accum_px + wpix0 + 8 * q, 0.f, 0.f, 0.f, &rgbx[q]);
+    }
   }
-  // tile-major hand-over: the 64 indices of this tile are 128 contiguous bytes; lanes outside the
+  // tile-major hand-over: the 64 indices of a tile are 128 contiguous bytes; lanes outside the
   // window write -1, so the consumer needs no bounds checks ...
   // ... and a header names the tile, so a record is self-describing for whoever loads it
   int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tiles8_x + (col0 >> 3)) * kVisTile;
-  rec[lane] = int16_t(idx);
-  if (lane == 0)
-    *reinterpret_cast<uint2*>(rec + 64) = make_uint2(uint32_t(col0 >> 3) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
-  if (p.out_rgb && last_sample && !p.defer_output) {
-    uint8_t* out = p.out_rgb + frame_px * 3;
-    const bool aligned = cols == 8 && (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
-    if (aligned) {
-      // lane l < 48 stores dword w = l % 6 of tile row r = l / 6: bytes 4w..4w+3 of the row's 24 come
-      // from pixels a = 4w / 3 and a + 1 (RGBX words of lanes 8r + a, 8r + a + 1)
-      const int r = (lane * 43) >> 8, w = lane - 6 * r;            // l / 6 for l < 64
-      const int hi3 = w >= 3 ? 1 : 0, a = w + hi3, m = w - 3 * hi3;
-      const int src = (8 * r + a) & 63;
-      const uint32_t lo = __builtin_amdgcn_ds_bpermute(src * 4, int(rgbx));
-      const uint32_t hi = __builtin_amdgcn_ds_bpermute(((src + 1) & 63) * 4, int(rgbx));
-      const unsigned long long six = (unsigned long long)lo | ((unsigned long long)hi << 24);
-      if (lane < 48 && r < rows)
-        *reinterpret_cast<uint32_t*>(out + ((size_t)(row0 + r) * p.nx + col0) * 3 + size_t(w) * 4) =
-            uint32_t(six >> (8 * m));
-    } else if (live) {
-      uint8_t* o = out + wpix * 3;
-      o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
+  uint8_t* out = p.out_rgb + frame_px * 3;
+  const bool write_rgb = p.out_rgb && last_sample && !p.defer_output;
+  const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+  // lane l < 48 stores dword w = l % 6 of tile row r = l / 6: bytes 4w..4w+3 of the row's 24 come
+  // from pixels a = 4w / 3 and a + 1 (RGBX words of lanes 8r + a, 8r + a + 1)
+  const int r = (lane * 43) >> 8, w = lane - 6 * r;            // l / 6 for l < 64
+  const int hi3 = w >= 3 ? 1 : 0, a = w + hi3, m = w - 3 * hi3;
+  const int src = (8 * r + a) & 63;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (cols[q] <= 0) break;                                  // wave-uniform: the second tile does not exist
+    rec[q * kVisTile + lane] = int16_t(idx[q]);
+    if (lane == 0)
+      *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
+          make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
+    if (write_rgb) {
+      if (cols[q] == 8 && dwords) {
+        const uint32_t lo = __builtin_amdgcn_ds_bpermute(src * 4, int(rgbx[q]));
+        const uint32_t hi = __builtin_amdgcn_ds_bpermute(((src + 1) & 63) * 4, int(rgbx[q]));
+        const unsigned long long six = (unsigned long long)lo | ((unsigned long long)hi << 24);
+        if (lane < 48 && r < rows)
+          *reinterpret_cast<uint32_t*>(out + ((size_t)(row0 + r) * p.nx + col0 + 8 * q) * 3 + size_t(w) * 4) =
+              uint32_t(six >> (8 * m));
+      } else if (live[q]) {
+        uint8_t* o = out + (wpix0 + 8 * q) * 3;
+        o[0] = uint8_t(rgbx[q]); o[1] = uint8_t(rgbx[q] >> 8); o[2] = uint8_t(rgbx[q] >> 16);
+      }
     }
   }
 }
@@ -1708,8 +1754,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     for (int s = 0; s < samples; ++s) {
       p.sample_index = s;
       if (stream_kernel) {
-        // one wave per 8x8 tile, 4 tiles (32 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
-        const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 31) / 32), unsigned(nf));
+        // one wave per pair of 8x8 tiles, 8 tiles (64 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
+        const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 63) / 64), unsigned(nf));
         const size_t vlds = 0;
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
