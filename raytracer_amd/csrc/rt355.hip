@@ -104,6 +104,13 @@ struct RenderParams {
   uint32_t seeds[kMaxBatch];
 };
 
+#ifndef RT_VIS_TILES
+#define RT_VIS_TILES 4     // 8x8 tiles (pixels per lane) of one visibility-pass wave: 2 -> +5 %, 4 -> +8 % on config 2 (87 VGPRs)
+#endif
+#ifndef RT_VIS_WAVES
+#define RT_VIS_WAVES 5     // its __launch_bounds__ occupancy target (waves per SIMD); 8 with 3+ tiles spills
+#endif
+constexpr int kVisTiles = RT_VIS_TILES;
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kVisTile = 72;       // int16 elements per tile record of RenderParams::vis (144 bytes)
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 cache lines
@@ -871,43 +878,50 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
 // the packed RGB rows of a tile (24 B each) are assembled across lanes with ds_bpermute.
 // ------------------------------------------------------------------------------------------
 template <int MODE, bool CUBES>
-__global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderParams p) {
-  // a wave covers two 8x8 tiles side by side: lane (lx, ly) traces pixel (lx, ly) of both
+__global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
+  // a wave covers kVisTiles 8x8 tiles side by side: lane (lx, ly) traces pixel (lx, ly) of each
+  constexpr int NT = kVisTiles;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * 4 + wave) * 16, row0 = int(blockIdx.x) * 8;   // window coordinates
+  const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), row0 = int(blockIdx.x) * 8;   // window coordinates
   const int lx = lane & 7, ly = lane >> 3;
   const int rows = min(8, p.n_rows - row0);
-  const int cols[2] = {min(8, p.nx - col0), min(8, p.nx - col0 - 8)};
+  int cols[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) cols[q] = min(8, p.nx - col0 - 8 * q);
   if (cols[0] <= 0) return;                               // wave-uniform: both tiles beyond the right edge
   const long long frame_px = (long long)frame * p.frame_stride_px;
   const long long accum_px = (long long)frame * p.accum_stride_px;
   const bool last_sample = p.sample_index + 1 == p.n_samples;
-  const bool live[2] = {lx < cols[0] && ly < rows, lx < cols[1] && ly < rows};
+  bool live[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) live[q] = lx < cols[q] && ly < rows;
   const long long wpix0 = (long long)(row0 + ly) * p.nx + (col0 + lx);      // second pixel: + 8
-  int idx[2] = {-1, -1};
-  uint32_t rgbx[2] = {0u, 0u};                            // hit pixels: placeholder
-  if (live[0]) {                                          // (live[1] implies live[0])
+  int idx[NT];
+  uint32_t rgbx[NT];                                      // hit pixels: placeholder
+#pragma unroll
+  for (int q = 0; q < NT; ++q) { idx[q] = -1; rgbx[q] = 0u; }
+  if (live[0]) {                                          // (a later tile's pixel is live only if the first one's is)
     const rt_camera& cam = p.cams[frame];
     const int y = tile_rows_uniform(p) ? tile_row_base(p, row0) + ly : row_of(p, row0 + ly);
-    float dx[2], dy[2], dz[2], t[2];
+    float dx[NT], dy[NT], dz[NT], t[NT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NT; ++q) {
       uint32_t pixel_key;
       primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + 8 * q + lx, y, p.sample_index, pixel_key, dx[q], dy[q],
                         dz[q]);
     }
-    primary_hit_n<2>(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
+    primary_hit_n<NT>(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
                      cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
       cgeom_t cg = as_const(p.cubes);
-      float ix[2], iy[2], iz[2];
+      float ix[NT], iy[NT], iz[NT];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) { ix[q] = frcp(dx[q]); iy[q] = frcp(dy[q]); iz[q] = frcp(dz[q]); }
+      for (int q = 0; q < NT; ++q) { ix[q] = frcp(dx[q]); iy[q] = frcp(dy[q]); iz[q] = frcp(dz[q]); }
       for (int c = 0; c < p.n_cubes; ++c) {
         const float4 lo = cg[2 * c], hi = cg[2 * c + 1];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NT; ++q) {
           float tc;
           int face;
           if (cube_t(lo, hi, cam.origin[0], cam.origin[1], cam.origin[2], dx[q], dy[q], dz[q], ix[q], iy[q], iz[q],
@@ -918,7 +932,7 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NT; ++q) {
       if (!live[q]) idx[q] = -1;
       if (live[q] && p.out_hit && last_sample) p.out_hit[frame_px + wpix0 + 8 * q] = idx[q];
       if (live[q] && idx[q] < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
@@ -938,8 +952,8 @@ __global__ __launch_bounds__(kBlock, 8) void rt_visibility_kernel(const RenderPa
   const int hi3 = w >= 3 ? 1 : 0, a = w + hi3, m = w - 3 * hi3;
   const int src = (8 * r + a) & 63;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (cols[q] <= 0) break;                                  // wave-uniform: the second tile does not exist
+  for (int q = 0; q < NT; ++q) {
+    if (cols[q] <= 0) break;                                  // wave-uniform: this tile and the ones after it do not exist
     rec[q * kVisTile + lane] = int16_t(idx[q]);
     if (lane == 0)
       *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
@@ -1755,7 +1769,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       p.sample_index = s;
       if (stream_kernel) {
         // one wave per pair of 8x8 tiles, 8 tiles (64 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
-        const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 63) / 64), unsigned(nf));
+        const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf));
         const size_t vlds = 0;
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
