@@ -92,6 +92,8 @@ struct RenderParams {
                            // outside the window) + header {tx | ty << 16, frame}; visibility pass -> stream kernel
   long long vis_stride;    // elements between frames of vis
   int* chunk_counter;      // dynamic work distribution of the stream kernel (zeroed per launch)
+  uint32_t* occ;           // [kTileCounters][occ_words] one bit per tile: some pixel of it hit something (zeroed per
+  int occ_words;           // launch, set by the visibility pass): word h * occ_words + (slot >> 5), bit slot & 31
   int tiles8_x, tiles8_y;
   uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
   float* out_f32;        // [frame][n_rows][nx][3] or null (render_chunk)
@@ -113,6 +115,7 @@ struct RenderParams {
 constexpr int kVisTiles = RT_VIS_TILES;
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kVisTile = 72;       // int16 elements per tile record of RenderParams::vis (144 bytes)
+constexpr int kTileCounters = 32;  // work counters of the stream kernel: tile id = slot * kTileCounters + counter
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 cache lines
 constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shadow | 8.. phase stamps
 #if RT_STAMPS
@@ -354,6 +357,14 @@ __device__ __forceinline__ void surface_normal(const float4* __restrict__ sg, in
     nx *= inv; ny *= inv; nz *= inv;
   }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const uint32_t __attribute__((address_space(4))) * cocc_t;
+__device__ __forceinline__ cocc_t as_const(const uint32_t* p) { return (cocc_t)(unsigned long long)(p); }
+#else
+typedef const uint32_t* cocc_t;
+__device__ __forceinline__ cocc_t as_const(const uint32_t* p) { return p; }
+#endif
 
 // table entry: four spheres, struct-of-arrays, so one s_load_dwordx16 brings a group and packed
 // VALU ops find sphere pairs in adjacent SGPRs.  w holds -c (or -inf where the camera is inside).
@@ -871,7 +882,7 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
 // find_nearest_intersection over all N spheres.  Output per pixel: the hit sphere index as int16
 // (2 B through L2/HBM; the consumer recomputes the hit distance with the same expressions), and
 // the frame itself — black where the ray misses (:237-238), a placeholder where the stream kernel
-// will write.  Per tile: the number of hit pixels, so the stream kernel visits only tiles with work.
+// will write.  Per tile: one occupancy bit (`occ`), so the stream kernel visits only tiles with work.
 // The kernel is issue-bound (profiles/r1e_*: ~500 instructions per wave, scalar ones included, and
 // gfx950 issues scalar and vector instructions of a SIMD's waves from one ~1.2 instr/ns budget:
 // profiles/r1_ubench_issue_mix.txt), so it has no LDS staging, no barrier and no per-lane divisions:
@@ -955,9 +966,17 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   for (int q = 0; q < NT; ++q) {
     if (cols[q] <= 0) break;                                  // wave-uniform: this tile and the ones after it do not exist
     rec[q * kVisTile + lane] = int16_t(idx[q]);
-    if (lane == 0)
+    const bool occupied = __ballot(idx[q] >= 0) != 0ull;
+    if (lane == 0) {
       *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
           make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
+      if (occupied) {   // tile id = slot * kTileCounters + counter (see the stream kernel's tile supply)
+        const uint32_t id = uint32_t(frame) * uint32_t(p.tiles8_x * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tiles8_x) +
+                            uint32_t(col0 >> 3) + uint32_t(q);
+        const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
+        atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
+      }
+    }
     if (write_rgb) {
       if (cols[q] == 8 && dwords) {
         const uint32_t lo = __builtin_amdgcn_ds_bpermute(src * 4, int(rgbx[q]));
@@ -1004,7 +1023,12 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 //     ~23 ns each on this part; K addresses work in parallel, and a claim of consecutive slots is K
 //     tiles apart in the frame: decorrelated.
 //   * guided self-scheduling: a claim is 1/(2 x waves per counter) of what its counter had left,
-//     between 1 and kClaimMax slots, so private backlogs shrink towards the end of the launch.
+//     between RT_CLAIM_MIN and kClaimMax slots, so private backlogs shrink towards the end of the launch.
+//   * only OCCUPIED tiles are loaded: the visibility pass sets one bit per tile in which some pixel
+//     hit something (`occ`, laid out per counter so that a claim's slots are consecutive bits); when
+//     a claim lands, the two words holding its bits are fetched by scalar loads, and a refill later
+//     they say which of its tiles exist for this kernel.  81 % of config 2's tiles are sky: taking
+//     each of them through the ring cost a quarter of the kernel's instruction issue.
 //   * nothing on the supply side waits for memory between two passes: the NEXT claim's atomic is in
 //     flight while the current claim is worked through, and the index data of the next kRing tiles
 //     is brought in by LDS-direct loads (global_load_lds_dword: 2 tiles = 256 bytes per instruction,
@@ -1018,14 +1042,19 @@ constexpr int kPendingCap = 128;                      // <= 63 left over + one t
 constexpr int kBounceCap = 64;                        // a pass takes ALL queued records (<= 64), then pushes <= 64
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
 #ifndef RT_RING
-#define RT_RING 4     // 4 keeps the kernel at 4 workgroups per CU up to 64 spheres (LDS); 8 and 16 measured no faster
+#define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
 constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
-constexpr int kTileCounters = 32;
 #ifndef RT_CLAIM
-#define RT_CLAIM 8
+#define RT_CLAIM 32    // slots per claim at most: one occupancy word's worth
 #endif
 constexpr int kClaimMax = RT_CLAIM;
+#ifndef RT_CLAIM_MIN
+#define RT_CLAIM_MIN 16 // slots per claim at least: ~3 occupied tiles at config 2's 19 % (with 1, the last claims of a launch are mostly empty: a round trip each)
+#endif
+#ifndef RT_GUIDE
+#define RT_GUIDE 2      // a claim is 1/(RT_GUIDE x waves per counter) of what its counter has left
+#endif
 
 constexpr int kBounceCapRefr = 192;                   // refraction: RT_MAX_DEPTH + 2 x 64, see the pass sizing in the kernel
 template <int CAP>
@@ -1083,19 +1112,24 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   // statically handed its first ceil((n_waves - h) / K) slots to the waves with number h mod K.
   auto first_of = [&](int h) { return (n_waves - h + kTileCounters - 1) / kTileCounters; };
   auto slots_of = [&](int h) { return (total_tiles - h + kTileCounters - 1) / kTileCounters; };
-  const int waves_per_counter2 = 2 * max(1, n_waves / kTileCounters);
+  const int waves_per_counter2 = RT_GUIDE * max(1, n_waves / kTileCounters);
   auto claim_size = [&](int h, int slot_seen) {   // from the counter position this wave saw last
-    return max(1, min(kClaimMax, (slots_of(h) - slot_seen) / waves_per_counter2));
+    return max(RT_CLAIM_MIN, min(kClaimMax, (slots_of(h) - slot_seen) / waves_per_counter2));
   };
   int hcur = gwave % kTileCounters;
   uint32_t dry = 0u;               // counters this wave has seen exhausted
   // (tile records are self-describing and lie in tile-id order, frame after frame, so the supply side
   // deals in tile ids only: no decoding into frame / row / column here)
-  int cl_left = 0, cl_id = 0;      // slots of the current claim not yet started, tile id of the next one
-  if (gwave < total_tiles) { cl_left = 1; cl_id = gwave; }
+  // current claim: occupancy bits (visibility pass: "some pixel of the tile hit something") of its
+  // slots not yet started, and the tile id of bit 0.  Empty tiles (81 % of config 2's) are never loaded.
+  uint32_t cl_mask = 0u;
+  int cl_base = 0;
+  if (gwave < total_tiles) { cl_mask = 1u; cl_base = gwave; }
   bool homeless = false;           // the counter this wave drew from is exhausted: it must find another
   int pf_n = 0, pf_c = 0;          // the claim being requested (lane 0 receives the counter value)
-  int nx_n = 0, nx_id = 0;         // the claim after the current one: slots, first tile id
+  bool nx_valid = false;           // the claim after the current one: slots, first tile id, and the two
+  int nx_n = 0, nx_id = 0, nx_shift = 0;   // occupancy words that hold its bits from bit nx_shift on (scalar
+  uint32_t nx_w0 = 0u, nx_w1 = 0u;         // loads issued when the claim lands, used a refill later)
   int seen = first_of(hcur);       // position of the home counter when this wave last looked
   // ---- ring of tiles whose index data is in LDS or on its way (FIFO: head = next to consume)
   uint32_t head = 0, tail = 0;     // tile counts
@@ -1121,15 +1155,21 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           const unsigned long long t0 = RT_NOW();
           for (;;) {
             bool asked = false;
-            if (nx_n == 0 && !homeless && cl_left < kRing) {
+            if (!nx_valid && !homeless && __popc(cl_mask) < kRing) {
               pf_n = claim_size(hcur, seen);
               if (lane == 0) pf_c = atomicAdd(p.chunk_counter + hcur * 32, pf_n);
               asked = true;
             }
             bool stalled = false;              // the ring has room but the next claim has not landed
             while (tail - head < uint32_t(kRing) && !supply_done) {
-              if (cl_left == 0) {
-                if (nx_n > 0) { cl_left = nx_n; nx_n = 0; cl_id = nx_id; continue; }
+              if (cl_mask == 0u) {
+                if (nx_valid) {
+                  const unsigned long long bits = (((unsigned long long)nx_w1 << 32) | nx_w0) >> nx_shift;
+                  cl_mask = uint32_t(bits) & (nx_n >= 32 ? 0xFFFFFFFFu : ((1u << nx_n) - 1u));
+                  cl_base = nx_id;
+                  nx_valid = false;
+                  continue;
+                }
                 if (homeless) {
                   // look (coherently) at all counters and move in with the first one, at or after the
                   // old home, that still has tiles; claims there go on through the same pipeline
@@ -1149,7 +1189,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
                 stalled = true;                // ask (again) at the top of the refill loop
                 break;
               }
-              if (cl_id >= total_tiles) { cl_left = 0; continue; }   // the rest of this claim lies beyond the end
+              // next occupied slot of the claim (slots beyond the last tile have no bit set)
+              const int cl_id = cl_base + (__ffs(int(cl_mask)) - 1) * kTileCounters;
+              cl_mask &= cl_mask - 1u;
               // ---- issue the tile: 36 lanes x 4 bytes (indices + header) straight into ring[slot]
               const uint32_t slot = tail & uint32_t(kRing - 1);
               if (lane < kVisTile / 2)
@@ -1157,13 +1199,15 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
                     (const __attribute__((address_space(1))) void*)(p.vis + (size_t)cl_id * kVisTile + lane * 2),
                     (__attribute__((address_space(3))) void*)(ring + slot * kVisTile), 4, 0, 0);
               ++tail;
-              --cl_left;
-              cl_id += kTileCounters;
             }
             if (asked) {                       // read the claim back
               const int slot = first_of(hcur) + __builtin_amdgcn_readfirstlane(pf_c);
               seen = slot + pf_n;
-              if (slot * kTileCounters + hcur < total_tiles) { nx_n = pf_n; nx_id = slot * kTileCounters + hcur; }
+              if (slot * kTileCounters + hcur < total_tiles) {
+                nx_valid = true; nx_n = pf_n; nx_id = slot * kTileCounters + hcur; nx_shift = slot & 31;
+                cocc_t w = as_const(p.occ) + size_t(hcur) * size_t(p.occ_words) + (slot >> 5);
+                nx_w0 = w[0]; nx_w1 = w[1];
+              }
               else { homeless = true; dry |= 1u << hcur; }
             }
             if (!stalled) break;               // else: go round again with the claim that has just landed
@@ -1588,7 +1632,8 @@ struct rt_ctx {
   unsigned long long* d_counters = nullptr;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
-  int* d_chunk = nullptr;        // stream kernel's chunk counters (kTileCounters, one per 128-byte line)
+  int* d_chunk = nullptr;        // stream kernel's tile counters (kTileCounters, one per 128-byte line), followed
+  size_t chunk_bytes = 0;        // by the occupancy words of the batch's tiles (grown on demand)
   size_t vis_elems = 0;
   int n_cus = 256;
   float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
@@ -1727,7 +1772,23 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
   p.vis = ctx->d_vis;
+  // tile occupancy: per counter one bit per slot, rounded up to words, plus one word of padding (a claim's
+  // bits are read as two words)
+  const long long batch_tiles = (long long)((w.nx + 7) / 8) * ((w.n_rows + 7) / 8) * batch;
+  const int occ_words = int(((batch_tiles + kTileCounters - 1) / kTileCounters + 31) / 32) + 1;
+  if (stream_kernel) {
+    const size_t need = size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4;
+    if (need > ctx->chunk_bytes) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_chunk) RT_HIP(ctx, hipFree(ctx->d_chunk));
+      ctx->d_chunk = nullptr; ctx->chunk_bytes = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_chunk, need));
+      ctx->chunk_bytes = need;
+    }
+  }
   p.chunk_counter = ctx->d_chunk;
+  p.occ = reinterpret_cast<uint32_t*>(ctx->d_chunk) + kTileCounters * 32;
+  p.occ_words = occ_words;
   p.tiles8_x = (w.nx + 7) / 8; p.tiles8_y = (w.n_rows + 7) / 8;
   p.counters = ctx->d_counters;
   p.frame_stride_px = frame_px;
@@ -1777,7 +1838,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         const unsigned per_cu = unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
         const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
-        RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, kTileCounters * 128, ctx->stream));
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4,
+                                   ctx->stream));
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes), vgrid, dim3(kBlock), vlds, ctx->stream, p);
         hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples)
@@ -1843,7 +1905,6 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_chunk, kTileCounters * 128)) != hipSuccess) return bail(e, "hipMalloc");
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMalloc");
