@@ -113,6 +113,10 @@ struct RenderParams {
 #define RT_VIS_WAVES 5     // its __launch_bounds__ occupancy target (waves per SIMD); 8 with 3+ tiles spills
 #endif
 constexpr int kVisTiles = RT_VIS_TILES;
+#ifndef RT_VIS_CULL_FROM
+#define RT_VIS_CULL_FROM 16   // scenes with more spheres than this: the visibility pass culls per wave (primary_hit_culled)
+#endif
+constexpr int kVisCullFrom = RT_VIS_CULL_FROM;
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kVisTile = 72;       // int16 elements per tile record of RenderParams::vis (144 bytes)
 constexpr int kTileCounters = 32;  // work counters of the stream kernel: tile id = slot * kTileCounters + counter
@@ -385,8 +389,44 @@ __host__ __device__ __forceinline__ int cam_groups_scanned(int n) { return (((n 
 __host__ __device__ __forceinline__ int cam_groups_stride(int n) { return cam_groups_scanned(n) + 1; }
 
 // NP rays per lane against the same table entries: the scalar loads, the loop and the candidate
-// branch are shared (the visibility pass traces two pixels per lane: it is issue-bound, and scalar
+// branch are shared (the visibility pass traces several pixels per lane: it is issue-bound, and scalar
 // instructions are ~40 % of what a one-pixel wave issues).
+template <int NP>
+__device__ __forceinline__ void test_cam_group(const CamGroup& grp, int g, cgeom_t geom, float ox, float oy, float oz,
+                                               const float (&dx)[NP], const float (&dy)[NP], const float (&dz)[NP],
+                                               const float (&inv_a)[NP], float (&best_t)[NP], int (&best_i)[NP]) {
+  float nb[NP][4], disc[NP][4];
+  uint32_t any = 0xFFFFFFFFu;
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      nb[q][j] = fmaf(grp.z[j], dz[q], fmaf(grp.y[j], dy[q], grp.x[j] * dx[q]));
+      disc[q][j] = fmaf(nb[q][j], nb[q][j], grp.negc[j]);
+      any &= __float_as_uint(disc[q][j]) | __float_as_uint(nb[q][j]);
+    }
+  if (int(any) >= 0) {
+    // some lane may hit one of these four spheres: decide and measure with the cancellation-free
+    // form of nearest_hit (the table's c carries a safety margin, so this is a superset)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        if (disc[q][j] >= 0.0f && nb[q][j] > 0.0f) {
+          float dl;
+          const float t = sphere_t_exact(geom[4 * g + j], ox, oy, oz, dx[q], dy[q], dz[q], inv_a[q], dl);
+          // (`<` between spheres of one group and of groups in index order; the culled scan below may
+          // visit groups in the same increasing order only, so ties still go to the lowest index)
+          if (dl >= 0.0f && t > 0.0f && t < best_t[q]) {
+            best_t[q] = t;
+            best_i[q] = 4 * g + j;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int NP>
 __device__ __forceinline__ void primary_hit_n(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
                                               int n, float ox, float oy, float oz, const float (&dx)[NP],
@@ -402,46 +442,63 @@ __device__ __forceinline__ void primary_hit_n(const float4* __restrict__ gg, con
   const int ngroups = cam_groups_scanned(n);   // padded with never-hit entries
   camtab_t tab = as_const(camtab);
   cgeom_t geom = as_const(gg);   // candidates are rare: their sphere comes by scalar load
-  auto test_group = [&](const CamGroup& grp, int g) {
-    float nb[NP][4], disc[NP][4];
-    uint32_t any = 0xFFFFFFFFu;
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        nb[q][j] = fmaf(grp.z[j], dz[q], fmaf(grp.y[j], dy[q], grp.x[j] * dx[q]));
-        disc[q][j] = fmaf(nb[q][j], nb[q][j], grp.negc[j]);
-        any &= __float_as_uint(disc[q][j]) | __float_as_uint(nb[q][j]);
-      }
-    if (int(any) >= 0) {
-      // some lane may hit one of these four spheres: decide and measure with the cancellation-free
-      // form of nearest_hit (the table's c carries a safety margin, so this is a superset)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          if (disc[q][j] >= 0.0f && nb[q][j] > 0.0f) {
-            float dl;
-            const float t = sphere_t_exact(geom[4 * g + j], ox, oy, oz, dx[q], dy[q], dz[q], inv_a[q], dl);
-            if (dl >= 0.0f && t > 0.0f && t < best_t[q]) {
-              best_t[q] = t;
-              best_i[q] = 4 * g + j;
-            }
-          }
-        }
-      }
-    }
-  };
   // Two groups per turn in two SGPR sets (no register-to-register rotation); each group's scalar
   // load is issued one group ahead of its arithmetic and the (rare) candidate branch.
   CamGroup a = tab[0];
   for (int g = 0; g < ngroups; g += 2) {
     const CamGroup b = tab[g + 1];
-    test_group(a, g);
+    test_cam_group<NP>(a, g, geom, ox, oy, oz, dx, dy, dz, inv_a, best_t, best_i);
     a = tab[g + 2];
-    test_group(b, g + 1);
+    test_cam_group<NP>(b, g + 1, geom, ox, oy, oz, dx, dy, dz, inv_a, best_t, best_i);
   }
 }
+
+// Bounding cone of a bundle of primary rays: unit axis, sin and cos^2 of the half-angle (with margin).
+struct RayCone {
+  float ax, ay, az, sin_t, cos2_t;
+};
+
+// The same scan for many spheres: the rays of a wave are a narrow bundle (a block of 8 x 8 NP pixels),
+// so first the WAVE culls — lane l tests sphere base + l against the bundle's bounding cone (the test
+// of lighting()'s per-lane cull: the sphere reaches into the cone iff perp cos(t) - along sin(t) <= r,
+// with the same slack) — and only table groups that hold a surviving sphere are tested per ray.
+// ~25 VALU per 64 spheres instead of 16 NP per 4.  Groups are still visited in increasing order.
+template <int NP>
+__device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
+                                                   int n, int lane, const RayCone& cone, float4 first_sphere,
+                                                   float ox, float oy, float oz, const float (&dx)[NP],
+                                                   const float (&dy)[NP], const float (&dz)[NP], float (&best_t)[NP],
+                                                   int (&best_i)[NP]) {
+  float inv_a[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    best_t[q] = INFINITY;
+    best_i[q] = -1;
+    inv_a[q] = frcp(fmaf(dz[q], dz[q], fmaf(dy[q], dy[q], dx[q] * dx[q])));
+  }
+  camtab_t tab = as_const(camtab);
+  cgeom_t geom = as_const(gg);
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const float4 s = base == 0 ? first_sphere : gg[i < n ? i : n - 1];
+    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+    const float d2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx)), r = fsqrt(s.w);
+    const float along = fmaf(cz, cone.az, fmaf(cy, cone.ay, cx * cone.ax));
+    const float perp2 = fmaxf(0.0f, fmaf(-along, along, d2));
+    const float rhs = fmaf(along, cone.sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
+    const bool keep = i < n && rhs >= 0.0f && rhs * rhs >= perp2 * cone.cos2_t;
+    unsigned long long m = __ballot(keep);
+    m |= m >> 1; m |= m >> 2;
+    m &= 0x1111111111111111ull;              // bit 4 k: group k of this chunk holds a sphere to test
+    while (m != 0ull) {
+      const int g = (base >> 2) + ((__ffsll((long long)m) - 1) >> 2);
+      m &= m - 1ull;
+      const CamGroup grp = tab[g];
+      test_cam_group<NP>(grp, g, geom, ox, oy, oz, dx, dy, dz, inv_a, best_t, best_i);
+    }
+  }
+}
+
 __device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
                                             int n, float ox, float oy, float oz, float dx, float dy,
                                             float dz, float& best_t, int& best_i) {
@@ -912,8 +969,13 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   uint32_t rgbx[NT];                                      // hit pixels: placeholder
 #pragma unroll
   for (int q = 0; q < NT; ++q) { idx[q] = -1; rgbx[q] = 0u; }
-  if (live[0]) {                                          // (a later tile's pixel is live only if the first one's is)
-    const rt_camera& cam = p.cams[frame];
+  // many spheres: the wave culls them against the bounding cone of its rays (primary_hit_culled); the
+  // first 64 spheres are requested now, so the load is covered by the ray set-up
+  const bool cull = p.n_spheres > kVisCullFrom;
+  float4 first_sphere = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cull) first_sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
+  if (live[0] || cull) {                                  // (a later tile's pixel is live only if the first one's is;
+    const rt_camera& cam = p.cams[frame];                 //  with the cull all lanes take part in its ballots)
     const int y = tile_rows_uniform(p) ? tile_row_base(p, row0) + ly : row_of(p, row0 + ly);
     float dx[NT], dy[NT], dz[NT], t[NT];
 #pragma unroll
@@ -922,8 +984,40 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
       primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + 8 * q + lx, y, p.sample_index, pixel_key, dx[q], dy[q],
                         dz[q]);
     }
-    primary_hit_n<NT>(p.geom, p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres), p.n_spheres, cam.origin[0],
-                     cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+    const CamGroup* table = p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres);
+    if (cull) {
+      // the block's rays: pixel x + r, y + r with r in [0, 1) -> u in [u0, u1], v in [v1, v0] (render_pixel
+      // :293-294); their directions right u + up v + forward form a planar patch, so the largest angle
+      // to the centre direction is at a corner
+      const int ya = tile_rows_uniform(p) ? tile_row_base(p, row0) : row_of(p, row0);
+      const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
+      const float u0 = float(p.x0 + col0) * p.inv_w * 2.0f - 1.0f, u1 = float(p.x0 + col0 + 8 * NT) * p.inv_w * 2.0f - 1.0f;
+      const float v0 = -(float(ya) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect, v1 = -(float(yb) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect;
+      const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1);
+      auto dir = [&](float u, float v, float& x, float& yy, float& z) {
+        x = fmaf(cam.up[0], v, cam.right[0] * u) + cam.forward[0];
+        yy = fmaf(cam.up[1], v, cam.right[1] * u) + cam.forward[1];
+        z = fmaf(cam.up[2], v, cam.right[2] * u) + cam.forward[2];
+        const float inv = frsq(fmaf(z, z, fmaf(yy, yy, x * x)));
+        x *= inv; yy *= inv; z *= inv;
+      };
+      RayCone cone;
+      dir(uc, vc, cone.ax, cone.ay, cone.az);
+      float cmin = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x, yy, z;
+        dir(k & 1 ? u1 : u0, k & 2 ? v1 : v0, x, yy, z);
+        cmin = fminf(cmin, fmaf(z, cone.az, fmaf(yy, cone.ay, x * cone.ax)));
+      }
+      cmin = fmaxf(0.0f, cmin - 1e-5f);                   // FP32 error of the above is ~1e-7
+      cone.cos2_t = cmin * cmin;
+      cone.sin_t = fsqrt(fmaxf(0.0f, 1.0f - cone.cos2_t));
+      primary_hit_culled<NT>(p.geom, table, p.n_spheres, lane, cone, first_sphere, cam.origin[0], cam.origin[1],
+                             cam.origin[2], dx, dy, dz, t, idx);
+    } else {
+      primary_hit_n<NT>(p.geom, table, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+    }
     if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
       cgeom_t cg = as_const(p.cubes);
       float ix[NT], iy[NT], iz[NT];
