@@ -107,6 +107,15 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
  * RT_KERNEL_PIXEL is refused. */
 int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refractive_index, int n_spheres);
 
+/* Host-only helper (needs no GPU, no context): the occluder table rt_upload_scene builds for the shadow
+ * scan of compute_lighting (raytracer.py:179-187, :198-202).  Row k (ceil(n/32) words) has bit c set if
+ * sphere c can be hit by some shadow ray that leaves sphere k towards either light — a conservative
+ * superset computed in FP64; the kernels test only these candidates (and still test them exactly).
+ * No counterpart in the reference (which tests every sphere for every ray); exported so that the
+ * superset property can be tested against brute force without a GPU.
+ * out_words: n * ceil(n/32) uint32. */
+int rt_occluder_table(const float* geom4, int n_spheres, const rt_lights* lights, uint32_t* out_words);
+
 /* Cube objects (raytracer.py:56-60) in the list find_nearest_intersection scans (:156-160, :164-169):
  * intersect_cube (:106-137) and cube_normal (:142-150).  n_cubes boxes, host pointers:
  *   box6[n][6] = min_point xyz, max_point xyz     mat4[n][4] = R, G, B, reflection     spec[n] = specular

@@ -84,6 +84,8 @@ struct RenderParams {
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
   const float2* refr;    // refraction, refractive_index (raytracer.py:43); only read by the REFR kernels
+  const uint32_t* occl;  // [objects][occl_words] bit c of row k: sphere c can shadow some point of object k (host table)
+  int occl_words;        // ceil(n_spheres / 32)
   const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
   int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
@@ -562,8 +564,8 @@ static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigne
 #endif
 template <int MODE, int B, bool REFR = false, bool CUBES = false>
 __device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg,
-                                         const float4* __restrict__ gg, const float2* __restrict__ refr, int n, int nc,
-                                         float px, float py, float pz, float nx, float ny, float nz,
+                                         const float4* __restrict__ gg, const float2* __restrict__ refr,
+                                         const uint32_t* __restrict__ occl_row, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          float mr, float mg, float mb, float spec, uint32_t level_key,
                                          float& lr, float& lg, float& lb) {
@@ -679,31 +681,38 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
       const float cos2_t = fmaf(-sin_t, sin_t, 1.0f);
       const float sin2_t = sin_t * sin_t * 1.0078125f;
       const bool wide = !(sin_t < 0.99f);   // P within (about) the light's bounding sphere: rays go anywhere
-      for (int cbase = 0; cbase < n; cbase += 32) {
-        const int cn = min(32, n - cbase);
+      for (int cbase = 0, word = 0; cbase < n; cbase += 32, ++word) {
+        // candidates: the spheres that can shadow SOME point of the object this lane shades (a table
+        // built at scene upload: every ray from the object towards a light lies in one cone, and few
+        // spheres reach into it).  Lanes shade different objects, so each walks its own bit list.
+        uint32_t cand = occl_row[word];
         uint32_t rel = 0u;
-        for (int j = cn - 1; j >= 0; --j) {   // (downwards: each verdict is shifted in at bit 0)
-          const float4 g = sg[cbase + j];   // wave-uniform address: LDS broadcast
-          const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
-          const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
-          const float d2 = c + g.w, r = fsqrt(g.w);
-          const float along = fmaf(cz, axz, fmaf(cy, axy, cx * axx));
-          const float al2 = along * along, perp2 = d2 - al2;
-          // sign bits do the logic (full-rate bit ops instead of half-rate compares): a set sign = "no"
-          //   rhs < 0 or rhs^2 < perp^2 cos^2 : out of the cone's reach
-          //   along < 0 and along^2 cos^2 > perp^2 sin^2 : every ray of the cone points away (nb < 0)
-          const float rhs = fmaf(along, sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
-          const float t2 = fmaf(rhs, rhs, -(perp2 * cos2_t));
-          const float e = fmaf(al2, cos2_t, -(perp2 * sin2_t));
-          uint32_t no = __float_as_uint(rhs) | __float_as_uint(t2) | (__float_as_uint(along) & ~__float_as_uint(e));
-          if (wide) no = 0u;
-          if (base == 0) {   // the point-light ray (k = 0): nb > 0 and nb^2 - c + 1.5 thr >= 0
-            const float nb = fmaf(cz, Lz[0], fmaf(cy, Ly[0], cx * Lx[0]));
-            const float q = fmaf(nb, nb, fmaf(d2, 1.5f / 262144.0f, -c));   // tier 1 acts on nb^2 - c + 2^-18 d2 >= 0
-            no &= __float_as_uint(nb) | __float_as_uint(q);
+        while (__ballot(cand != 0u) != 0ull) {
+          if (cand != 0u) {
+            const int j = __ffs(int(cand)) - 1;
+            cand &= cand - 1u;
+            const float4 g = sg[cbase + j];   // per-lane LDS read
+            const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
+            const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
+            const float d2 = c + g.w, r = fsqrt(g.w);
+            const float along = fmaf(cz, axz, fmaf(cy, axy, cx * axx));
+            const float al2 = along * along, perp2 = d2 - al2;
+            // sign bits do the logic (full-rate bit ops instead of half-rate compares): a set sign = "no"
+            //   rhs < 0 or rhs^2 < perp^2 cos^2 : out of the cone's reach
+            //   along < 0 and along^2 cos^2 > perp^2 sin^2 : every ray of the cone points away (nb < 0)
+            const float rhs = fmaf(along, sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
+            const float t2 = fmaf(rhs, rhs, -(perp2 * cos2_t));
+            const float e = fmaf(al2, cos2_t, -(perp2 * sin2_t));
+            uint32_t no = __float_as_uint(rhs) | __float_as_uint(t2) | (__float_as_uint(along) & ~__float_as_uint(e));
+            if (wide) no = 0u;
+            if (base == 0) {   // the point-light ray (k = 0): nb > 0 and nb^2 - c + 1.5 thr >= 0
+              const float nb = fmaf(cz, Lz[0], fmaf(cy, Ly[0], cx * Lx[0]));
+              const float q = fmaf(nb, nb, fmaf(d2, 1.5f / 262144.0f, -c));   // tier 1 acts on nb^2 - c + 2^-18 d2 >= 0
+              no &= __float_as_uint(nb) | __float_as_uint(q);
+            }
+            no |= __float_as_uint(c);           // origin inside the sphere: never hit
+            rel |= (~no >> 31) << j;
           }
-          no |= __float_as_uint(c);           // origin inside the sphere: never hit
-          rel = __builtin_amdgcn_alignbit(rel, ~no, 31);   // rel = rel << 1 | (sign clear)
         }
 #if RT_CULL_STATS
         g_dbg_rel += __popc(rel); g_dbg_lanes += 1;
@@ -820,7 +829,7 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
   float lr, lg, lb;
-  lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+  lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                m.x, m.y, m.z, spec, level_key, lr, lg, lb);
   load_state();
   const float refl = m.w;
@@ -1442,7 +1451,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
           const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
           float lr, lg, lb;
-          lighting<MODE, 1, true, CUBES>(p.L, sg, p.geom, p.refr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
+          lighting<MODE, 1, true, CUBES>(p.L, sg, p.geom, p.refr, nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
                                   sx, sy, sz, m.x, m.y, m.z, spec, mix(pixel_key, uint32_t(level + 1)), lr, lg, lb);
           late_state();
           s2 = RT_NOW();
@@ -1721,6 +1730,7 @@ struct rt_ctx {
   float2* d_refr = nullptr;      // refraction, refractive_index per object (rt_set_refraction, rt_set_cubes)
   bool has_refr = false;         // some sphere has refraction > 0: the REFR kernels run
   bool has_refr_cubes = false;   // some cube has
+  uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
   unsigned long long* d_counters = nullptr;
@@ -1777,6 +1787,49 @@ float rcp_rn(int n) {
 struct Window {
   int x0, nx, n_rows, tile_rows, tile_first, tile_stride, y0;
 };
+
+// Occluder table for lighting()'s shadow scan: bit c of row k says that sphere c can be hit by SOME
+// shadow ray that leaves sphere k (raytracer.py:184, :199: origins lie 0.001 off its surface) towards
+// the point light or any point of the area light.  All such rays start inside the ball (K, rho) and
+// pass through the ball (A, R) of the light, so they stay inside the cone that contains the first
+// ball and has half-angle asin((rho + R) / |A - K|) about K -> A; a sphere matters only if it reaches
+// into that cone.  FP64, with margins far above the kernel's FP32 error: a superset, and the kernel
+// still applies its per-point cull and the exact test to every candidate, so results do not change.
+void build_occluder_table(const float* geom4, int n, const DevLights& L, std::vector<uint32_t>& tab) {
+  const int words = (n + 31) / 32;
+  tab.assign(size_t(std::max(n, 1)) * size_t(std::max(words, 1)), 0u);
+  struct Ball { double x, y, z, r; };
+  const Ball lights[2] = {{L.ppos[0], L.ppos[1], L.ppos[2], 1e-4},
+                          {L.apos[0], L.apos[1], L.apos[2], double(L.arad) * 1.001 + 1e-4}};
+  for (int k = 0; k < n; ++k) {
+    const double kx = geom4[4 * k], ky = geom4[4 * k + 1], kz = geom4[4 * k + 2];
+    const double rho = std::sqrt(double(geom4[4 * k + 3])) * 1.001 + 2e-3;
+    uint32_t* row = tab.data() + size_t(k) * size_t(words);
+    bool all = false;
+    for (const Ball& A : lights) {
+      const double ax = A.x - kx, ay = A.y - ky, az = A.z - kz;
+      const double d = std::sqrt(ax * ax + ay * ay + az * az);
+      if (!(d > (rho + A.r) * 1.01)) { all = true; break; }    // the light is (nearly) inside the ball: rays go anywhere
+      const double ux = ax / d, uy = ay / d, uz = az / d;
+      const double sn = (rho + A.r) / d, cs = std::sqrt(1.0 - sn * sn);
+      const double back = rho / sn;                            // apex of the cone that contains the ball (K, rho)
+      const double px = kx - ux * back, py = ky - uy * back, pz = kz - uz * back;
+      for (int c = 0; c < n; ++c) {
+        const double cx = geom4[4 * c] - px, cy = geom4[4 * c + 1] - py, cz = geom4[4 * c + 2] - pz;
+        const double d2 = cx * cx + cy * cy + cz * cz;
+        const double along = cx * ux + cy * uy + cz * uz;
+        const double perp = std::sqrt(std::max(0.0, d2 - along * along));
+        const double rc = std::sqrt(double(geom4[4 * c + 3]));
+        if (perp * cs - along * sn <= rc * 1.001 + 1e-3 * (1.0 + std::sqrt(d2))) row[c >> 5] |= 1u << (c & 31);
+      }
+    }
+#if defined(RT_OCCL_ALL)   // A/B and verification builds: no table culling (every sphere is a candidate)
+    all = true;
+#endif
+    if (all)
+      for (int c = 0; c < n; ++c) row[c >> 5] |= 1u << (c & 31);
+  }
+}
 
 // kernel variants: RNG mode x refraction in the scene x cubes in the scene
 using RenderKernel = void (*)(const RenderParams);
@@ -1862,6 +1915,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.n_spheres = ctx->n_spheres;
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
   p.cubes = ctx->d_cubes; p.n_cubes = ctx->n_cubes;
+  p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32;
   p.defer_output = refr ? 1 : 0;
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
@@ -1997,6 +2051,8 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_refr, sizeof(float2) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
+    return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -2026,6 +2082,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_spec) (void)hipFree(ctx->d_spec);
   if (ctx->d_refr) (void)hipFree(ctx->d_refr);
   if (ctx->d_cubes) (void)hipFree(ctx->d_cubes);
+  if (ctx->d_occl) (void)hipFree(ctx->d_occl);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -2097,6 +2154,11 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   L.aint = lights->area_intensity; L.ns = lights->area_samples;
   L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
                    std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
+  if (n_spheres > 0) {
+    std::vector<uint32_t> occl;
+    build_occluder_table(geom4, n_spheres, L, occl);
+    RT_HIP(ctx, hipMemcpy(ctx->d_occl, occl.data(), sizeof(uint32_t) * occl.size(), hipMemcpyHostToDevice));
+  }
   ctx->n_spheres = n_spheres;
   ctx->has_refr = false;   // Material's defaults (raytracer.py:43) until rt_set_refraction says otherwise
   ctx->n_cubes = 0;        // the object list holds spheres only until rt_set_cubes says otherwise
@@ -2137,9 +2199,33 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
     RT_HIP(ctx, hipMemcpy(ctx->d_mat + at, mat4, sizeof(float4) * size_t(n_cubes), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_spec + at, spec, sizeof(float) * size_t(n_cubes), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_refr + at, rf.data(), sizeof(float2) * size_t(n_cubes), hipMemcpyHostToDevice));
+    // occluder table rows of the cubes: every sphere may shadow a point of a box
+    const int words = (ctx->n_spheres + 31) / 32;
+    if (words > 0) {
+      std::vector<uint32_t> rows(size_t(n_cubes) * size_t(words), 0u);
+      for (int i = 0; i < n_cubes; ++i)
+        for (int c = 0; c < ctx->n_spheres; ++c) rows[size_t(i) * size_t(words) + size_t(c >> 5)] |= 1u << (c & 31);
+      RT_HIP(ctx, hipMemcpy(ctx->d_occl + at * size_t(words), rows.data(), sizeof(uint32_t) * rows.size(),
+                            hipMemcpyHostToDevice));
+    }
   }
   ctx->n_cubes = n_cubes;
   ctx->has_refr_cubes = any;
+  return RT_OK;
+}
+
+int rt_occluder_table(const float* geom4, int n_spheres, const rt_lights* lights, uint32_t* out_words) {
+  if (n_spheres < 0 || n_spheres > RT_MAX_SPHERES || !lights || !out_words || (n_spheres > 0 && !geom4))
+    return fail(nullptr, RT_EINVAL, "rt_occluder_table: bad argument");
+  DevLights L{};
+  memcpy(L.ppos, lights->point_pos, 12);
+  memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
+  L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
+                   std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
+  std::vector<uint32_t> tab;
+  build_occluder_table(geom4, n_spheres, L, tab);
+  const size_t words = size_t(n_spheres) * size_t((n_spheres + 31) / 32);
+  if (words) memcpy(out_words, tab.data(), words * sizeof(uint32_t));
   return RT_OK;
 }
 

@@ -142,3 +142,43 @@ def test_presentation_helpers(tmp_path):
         assert np.array_equal(np.asarray(Image.open(q)), img)
     with pytest.raises(ValueError):
         present.as_host_rgb(img.astype(np.float32))
+
+
+def test_occluder_table_is_a_superset_of_brute_force():
+    """rt_occluder_table (host-only, FP64): every sphere that a shadow ray leaving sphere k towards the
+    point light or any point of the area light can hit must have its bit set in row k.  Brute force:
+    random points on each sphere, offset 0.001 along the normal (raytracer.py:184, :199), rays to the
+    point light and to the corners / random points of the area light, intersect_sphere (:93-104)."""
+    import ctypes
+    from raytracer_amd import _lib
+    from raytracer_amd.scenes import generate_scene, pack_scene, default_scene
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    for scene in (default_scene(), generate_scene(8, 1, keep_default=True), generate_scene(64, 2), generate_scene(150, 7)):
+        p = pack_scene(scene)
+        n, words = p.n_spheres, (p.n_spheres + 31) // 32
+        out = np.zeros((n, words), np.uint32)
+        lights = p.ct_lights()
+        g = np.ascontiguousarray(p.geom4, np.float32)
+        assert L.rt_occluder_table(g.ctypes.data, n, ctypes.byref(lights), out.ctypes.data) == 0
+        bits = ((out[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)[:, :n].astype(bool)
+        C = p.geom4[:, :3].astype(np.float64); r = np.sqrt(p.geom4[:, 3].astype(np.float64))
+        lv = p.lights.astype(np.float64)
+        ppos, apos, au, av = lv[0:3], lv[7:10], lv[10:13], lv[13:16]
+        targets = [ppos] + [apos + au * a + av * b for a in (-0.5, 0.5) for b in (-0.5, 0.5)] + \
+                  [apos + au * (rng.random() - 0.5) + av * (rng.random() - 0.5) for _ in range(6)]
+        hit_any = np.zeros((n, n), bool)
+        for k in range(n):
+            d = rng.normal(size=(400, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+            S = C[k] + d * (r[k] + 0.001)
+            for T in targets:
+                Ld = T - S; Ld /= np.linalg.norm(Ld, axis=1, keepdims=True)
+                oc = S[:, None, :] - C[None, :, :]                     # [pts, spheres, 3]
+                b = 2 * np.einsum("psk,pk->ps", oc, Ld)
+                c = np.einsum("psk,psk->ps", oc, oc) - r[None, :] ** 2
+                disc = b * b - 4 * c
+                t = (-b - np.sqrt(np.maximum(disc, 0))) / 2
+                hit_any[k] |= ((disc >= 0) & (t > 0)).any(axis=0)
+        assert not (hit_any & ~bits).any(), "a sphere that is hit is missing from the table"
+        if n >= 64:      # and the table is selective: a few candidates per object, not all of them
+            assert bits.sum(1).mean() < 0.25 * n
