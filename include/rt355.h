@@ -85,8 +85,12 @@ int rt_synchronize(rt_ctx* ctx);
  *   RT_OPT_KERNEL: RT_KERNEL_STREAM (default) = visibility pass (primary rays) followed by the
  *   persistent-wave shading kernel that compacts hits into dense 64-lane passes; RT_KERNEL_PIXEL = one
  *   thread per pixel, whole path in one loop (kept as the baseline for divergence counters).  Both
- *   compute the same arithmetic per ray. */
+ *   compute the same arithmetic per ray.
+ *   RT_OPT_OCCLUDER_TABLE: 1 (default) = the shadow scan of a hit on object k only looks at the spheres
+ *   that can shadow some point of k (see rt_occluder_table); 0 = at every sphere, as the reference
+ *   does.  Images are byte-identical either way (tests); takes effect at the next rt_upload_scene. */
 #define RT_OPT_KERNEL 1
+#define RT_OPT_OCCLUDER_TABLE 2
 #define RT_KERNEL_STREAM 0
 #define RT_KERNEL_PIXEL 1
 int rt_set_option(rt_ctx* ctx, int option, int value);

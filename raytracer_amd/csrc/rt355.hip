@@ -1744,6 +1744,7 @@ struct rt_ctx {
   size_t accum_floats = 0;
   int n_spheres = -1;
   int kernel = RT_KERNEL_STREAM;
+  bool occluder_table = true;    // RT_OPT_OCCLUDER_TABLE: false = every sphere is a candidate for every object
   unsigned long long host_primaries = 0;  // primary rays of the visibility pass (one per pixel and sample), counted here
   DevLights lights{};
   std::string err;
@@ -1795,7 +1796,8 @@ struct Window {
 // ball and has half-angle asin((rho + R) / |A - K|) about K -> A; a sphere matters only if it reaches
 // into that cone.  FP64, with margins far above the kernel's FP32 error: a superset, and the kernel
 // still applies its per-point cull and the exact test to every candidate, so results do not change.
-void build_occluder_table(const float* geom4, int n, const DevLights& L, std::vector<uint32_t>& tab) {
+void build_occluder_table(const float* geom4, int n, const DevLights& L, std::vector<uint32_t>& tab,
+                          bool selective = true) {
   const int words = (n + 31) / 32;
   tab.assign(size_t(std::max(n, 1)) * size_t(std::max(words, 1)), 0u);
   struct Ball { double x, y, z, r; };
@@ -1805,8 +1807,9 @@ void build_occluder_table(const float* geom4, int n, const DevLights& L, std::ve
     const double kx = geom4[4 * k], ky = geom4[4 * k + 1], kz = geom4[4 * k + 2];
     const double rho = std::sqrt(double(geom4[4 * k + 3])) * 1.001 + 2e-3;
     uint32_t* row = tab.data() + size_t(k) * size_t(words);
-    bool all = false;
+    bool all = !selective;        // RT_OPT_OCCLUDER_TABLE off (verification runs): every sphere is a candidate
     for (const Ball& A : lights) {
+      if (all) break;
       const double ax = A.x - kx, ay = A.y - ky, az = A.z - kz;
       const double d = std::sqrt(ax * ax + ay * ay + az * az);
       if (!(d > (rho + A.r) * 1.01)) { all = true; break; }    // the light is (nearly) inside the ball: rays go anywhere
@@ -1823,9 +1826,6 @@ void build_occluder_table(const float* geom4, int n, const DevLights& L, std::ve
         if (perp * cs - along * sn <= rc * 1.001 + 1e-3 * (1.0 + std::sqrt(d2))) row[c >> 5] |= 1u << (c & 31);
       }
     }
-#if defined(RT_OCCL_ALL)   // A/B and verification builds: no table culling (every sphere is a candidate)
-    all = true;
-#endif
     if (all)
       for (int c = 0; c < n; ++c) row[c >> 5] |= 1u << (c & 31);
   }
@@ -2105,6 +2105,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
     ctx->kernel = value;
     return RT_OK;
   }
+  if (option == RT_OPT_OCCLUDER_TABLE && (value == 0 || value == 1)) {
+    ctx->occluder_table = value != 0;   // takes effect at the next rt_upload_scene
+    return RT_OK;
+  }
   return fail(ctx, RT_EINVAL, "unknown option %d / value %d", option, value);
 }
 
@@ -2156,7 +2160,7 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
                    std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
   if (n_spheres > 0) {
     std::vector<uint32_t> occl;
-    build_occluder_table(geom4, n_spheres, L, occl);
+    build_occluder_table(geom4, n_spheres, L, occl, ctx->occluder_table);
     RT_HIP(ctx, hipMemcpy(ctx->d_occl, occl.data(), sizeof(uint32_t) * occl.size(), hipMemcpyHostToDevice));
   }
   ctx->n_spheres = n_spheres;

@@ -189,6 +189,11 @@ class Renderer:
         v = {"stream": _lib.RT_KERNEL_STREAM, "pixel": _lib.RT_KERNEL_PIXEL}[name]
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_KERNEL, v))
 
+    def set_occluder_table(self, on: bool):
+        """Shadow scan over the per-object candidate table (default) or over every sphere; same images.
+        Takes effect at the next upload_scene."""
+        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_OCCLUDER_TABLE, 1 if on else 0))
+
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
         torch = _torch()

@@ -221,6 +221,30 @@ def test_cubes_abi(renderer):
     assert torch.equal(b, renderer.render(200, 120, 1, rng_mode="K", seed=3)) and not torch.equal(b, one)
 
 
+def test_occluder_table_changes_no_byte(renderer):
+    """The shadow scan restricted to rt_occluder_table's candidates renders the same bytes and hit maps as
+    the scan over every sphere (what the reference does), from 3 to 1024 spheres, with cubes, other
+    cameras and light sample counts."""
+    import torch
+    from raytracer_amd.scenes import cube_scene
+    cases = [(default_scene(), 640, 480, 5), (generate_scene(8, 1, keep_default=True), 1920, 1080, 5),
+             (generate_scene(64, 2), 1920, 1080, 5), (generate_scene(64, 2), 960, 540, 8),
+             (generate_scene(200, 5), 640, 360, 5), (generate_scene(1024, 3), 960, 540, 5), (cube_scene(), 640, 360, 5)]
+    cases[3][0]["area_light"].samples = 20
+    try:
+        for scene, w, h, D in cases:
+            out = []
+            for on in (True, False):
+                renderer.set_occluder_table(on)
+                renderer.upload_scene(scene)
+                out.append([renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=9, camera=cam, return_hit_index=True)
+                            for cam in (None, orbit_camera(37, 256), orbit_camera(150, 256))])
+            for (a, ha), (b, hb) in zip(*out):
+                assert torch.equal(a, b) and torch.equal(ha, hb)
+    finally:
+        renderer.set_occluder_table(True)
+
+
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
     pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""
