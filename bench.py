@@ -225,12 +225,15 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                          "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
-                                    "also cover the ~4 us rt_camera_table_kernel and a 4 KB memset)")
+                                    "also cover the ~4 us rt_camera_table_kernel and a 0.26 MB memset)")
                          if args.kernel == "stream" else "rt_pixel_kernel", "kernel_ms": kern_ms,
                          "flops_per_launch": fl,
                          "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d, i.e. "
-                                 "the brute-force count: the kernels cull spheres per lane and execute fewer; "
-                                 "HBM traffic (PMC, profiles/) is the framebuffer + 2.25 B/pixel of hit indices"},
+                                 "the brute-force count of the reference's algorithm: the kernels cull spheres (per object, per "
+                                 "shading point, per ray bundle) and execute ~3x fewer flops, so frac exceeds 1 on "
+                                 "many-sphere scenes (DESIGN.md 4, roofline); HBM traffic (PMC, profiles/r1j_*) is "
+                                 "~1.8e9 B per config-2 launch: the framebuffer, 2.25 B/pixel of hit indices and the "
+                                 "scattered pixel stores"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
