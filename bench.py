@@ -126,7 +126,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    from raytracer_amd.distributed import gather_row_tiles
+    from raytracer_amd.distributed import BatchExchange
     from raytracer_amd.render import Renderer
     from raytracer_amd.scenes import pack_scene
     from raytracer_amd import tiling
@@ -142,11 +142,14 @@ def main():
     rows_max = tiling.max_local_rows(h, tr, world)
     slab_bytes = rows_max * w * 3
     dev = f"cuda:{local_rank}"
-    # this rank's packed tiles of the F frames of a step (N > 1 only)
-    slab = torch.zeros((F, slab_bytes), dtype=torch.uint8, device=dev) if world > 1 else None
     if rank == 0:
-        gathered = torch.empty((world, F, slab_bytes), dtype=torch.uint8, device=dev) if world > 1 else None
         frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device=dev)
+    # N > 1: every rank renders its row tiles of the F frames of a step into a slab; one gather per step
+    # moves the slabs to GPU 0, where one launch puts the rows in image order.  Double-buffered: the
+    # gather of step i (RCCL's stream) overlaps the render of step i + 1.
+    ex = BatchExchange(F, slab_bytes, dev,
+                       lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out)) \
+        if (world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE")) else None   # (env: rehearse this path on 1 GPU)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
@@ -154,21 +157,20 @@ def main():
     cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
 
     def step(i, timed_idx=None):
+        # N = 1: the rank owns every row, so its packed slab IS the frame batch
+        out = frames_out if ex is None else ex.slab(i).view(F, rows_max, w, 3)
         if timed_idx is not None:
             ev[timed_idx][0].record()
-        # N = 1: the rank owns every row, so its packed slab IS the frame batch
-        out = frames_out if world == 1 else slab.view(F, rows_max, w, 3)
         r.render_frames(cams, range(i * F, (i + 1) * F), w, h, args.samples, max_depth=D, rng_mode="K",
                         out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
         if timed_idx is not None:
             ev[timed_idx][1].record()
-        if world > 1:
-            dist.gather(slab, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                for f in range(F):
-                    r.scatter_rows(gathered[:, f], world, w, h, tr, out=frames_out[f])
+        if ex is not None:
+            ex.submit(i)
 
     def barrier():
+        if ex is not None:
+            ex.drain()         # the last steps' gathers and placements belong to the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

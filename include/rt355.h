@@ -187,6 +187,12 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, 
  * out_rgb: device uint8 [height][width][3]. */
 int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_bytes, int n_ranks,
                     int width, int height, int tile_rows, uint8_t* out_rgb);
+/* The same for a batch: frame f of rank r starts at gathered + r * rank_stride_bytes + f * frame_stride_bytes
+ * (the layout a gather of rt_render_frames_rows slabs produces); out_rgb: [n_frames][height][width][3].
+ * One launch for the whole batch. */
+int rt_scatter_rows_frames(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_bytes,
+                           int64_t frame_stride_bytes, int n_ranks, int n_frames, int width, int height,
+                           int tile_rows, uint8_t* out_rgb);
 
 /* Ray statistics accumulated by every render call since the last reset (device counters; this
  * call synchronises the stream).  out[0] = primary rays, out[1] = reflection rays,

@@ -1674,7 +1674,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_pixel_kernel(con
 __global__ __launch_bounds__(256) void rt_scatter_rows_kernel(const uint8_t* __restrict__ gathered,
                                                               long long rank_stride, int n_ranks,
                                                               int width, int height, int tile_rows,
-                                                              uint8_t* __restrict__ out, int vec4) {
+                                                              uint8_t* __restrict__ out, int vec4,
+                                                              long long frame_stride_in, long long frame_stride_out) {
+  gathered += (long long)blockIdx.z * frame_stride_in;      // batch of frames: one per grid z
+  out += (long long)blockIdx.z * frame_stride_out;
   const int y = blockIdx.y;
   const int t = y / tile_rows;
   const int r = t % n_ranks, j = t / n_ranks;
@@ -2327,22 +2330,32 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, 
 
 int rt_scatter_rows(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_bytes, int n_ranks,
                     int width, int height, int tile_rows, uint8_t* out_rgb) {
+  return rt_scatter_rows_frames(ctx, gathered, rank_stride_bytes, 0, n_ranks, 1, width, height, tile_rows, out_rgb);
+}
+
+int rt_scatter_rows_frames(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_stride_bytes,
+                           int64_t frame_stride_bytes, int n_ranks, int n_frames, int width, int height,
+                           int tile_rows, uint8_t* out_rgb) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (!gathered || !out_rgb) return fail(ctx, RT_EINVAL, "gathered/out_rgb is NULL");
-  if (n_ranks < 1 || width <= 0 || height <= 0 || tile_rows < 1 || height > 65535)
+  if (n_ranks < 1 || width <= 0 || height <= 0 || tile_rows < 1 || height > 65535 || n_frames < 1 || n_frames > 65535)
     return fail(ctx, RT_EINVAL, "bad scatter arguments");
+  if (n_frames > 1 && frame_stride_bytes < rows_owned(height, tile_rows, 0, n_ranks) * (long long)width * 3)
+    return fail(ctx, RT_EINVAL, "frame_stride_bytes %lld too small", (long long)frame_stride_bytes);
   // every rank's slab must hold its rows
   const long long max_rows = rows_owned(height, tile_rows, 0, n_ranks);
   if (rank_stride_bytes < 0 || (n_ranks > 1 && rank_stride_bytes < max_rows * width * 3))
     return fail(ctx, RT_EINVAL, "rank_stride_bytes %lld too small", (long long)rank_stride_bytes);
   const long long row_bytes = (long long)width * 3;
-  const int vec4 = (row_bytes % 4 == 0) && (rank_stride_bytes % 4 == 0) &&
+  const int vec4 = (row_bytes % 4 == 0) && (rank_stride_bytes % 4 == 0) && (frame_stride_bytes % 4 == 0) &&
+                   (((long long)height * row_bytes) % 4 == 0) &&
                    ((reinterpret_cast<uintptr_t>(gathered) | reinterpret_cast<uintptr_t>(out_rgb)) % 4 == 0);
   const int per_row = int(vec4 ? row_bytes / 4 : row_bytes);
   const unsigned gx = unsigned(std::min(8, (per_row + 255) / 256));
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(rt_scatter_rows_kernel, dim3(gx, unsigned(height), 1), dim3(256), 0, ctx->stream,
-                     gathered, (long long)rank_stride_bytes, n_ranks, width, height, tile_rows, out_rgb, vec4);
+  hipLaunchKernelGGL(rt_scatter_rows_kernel, dim3(gx, unsigned(height), unsigned(n_frames)), dim3(256), 0, ctx->stream,
+                     gathered, (long long)rank_stride_bytes, n_ranks, width, height, tile_rows, out_rgb, vec4,
+                     (long long)frame_stride_bytes, (long long)height * row_bytes);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }

@@ -59,6 +59,57 @@ def gather_row_tiles(local, width: int, height: int, tile_rows: int, group=None,
     return out
 
 
+class BatchExchange:
+    """Double-buffered exchange of frame batches: the gather of batch i runs (on the collective's own
+    stream) while batch i + 1 is rendered, and the root places batch i after it has launched batch i + 1.
+
+    Per step every rank calls ``slab = ex.slab(i)``, renders its row tiles of the batch into it, then
+    ``ex.submit(i)``.  ``ex.drain()`` finishes what is in flight.  ``place(gathered, i)`` runs on the root
+    when batch i has arrived (``gathered``: [world, F, slab_bytes]).  Buffers: two slabs per rank, two
+    gather buffers on the root.  With ``world == 1`` the slab is handed to ``place`` directly.
+    Works with nccl (GPU tensors) and gloo (CPU tensors; used by the CPU tests of this logic)."""
+
+    def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group, self.dst, self.place = dist, group, dst, place
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.slabs = [torch.zeros((n_frames, slab_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
+                         for _ in range(2)] if (self.rank == dst and self.world > 1) else [None, None]
+        self.pending = [None, None]      # (work handle, step) of the batch in flight in each buffer
+
+    def slab(self, step: int):
+        self._finish(step & 1)           # the batch that used this buffer two steps ago must be gone
+        return self.slabs[step & 1]
+
+    def submit(self, step: int):
+        b = step & 1
+        if self.world == 1:
+            self.place(self.slabs[b].unsqueeze(0), step)
+            return
+        parts = list(self.gathered[b].unbind(0)) if self.rank == self.dst else None
+        work = self.dist.gather(self.slabs[b], parts, dst=self.dst, group=self.group, async_op=True)
+        self.pending[b] = (work, step)
+        self._finish(1 - b)              # the previous batch: its gather overlapped this batch's render
+
+    def _finish(self, b: int):
+        if self.pending[b] is None:
+            return
+        work, step = self.pending[b]
+        self.pending[b] = None
+        work.wait()                      # nccl: the current stream waits; gloo: the host does
+        if self.rank == self.dst:
+            self.place(self.gathered[b], step)
+
+    def drain(self):
+        # in submission order
+        order = sorted((p[1], b) for b, p in enumerate(self.pending) if p is not None)
+        for _, b in order:
+            self._finish(b)
+
+
 def render_distributed(renderer, width, height, samples=1, *, tile_rows=DEFAULT_TILE_ROWS,
                        group=None, max_depth=5, camera=None, rng_mode="keyed", seed=0,
                        buffers: dict | None = None):

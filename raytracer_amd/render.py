@@ -207,6 +207,21 @@ class Renderer:
                                             n_ranks, width, height, tile_rows, out.data_ptr()))
         return out
 
+    def scatter_rows_frames(self, gathered, n_ranks, width, height, tile_rows, out=None):
+        """The same for a batch in one launch: [n_ranks, F, slab_bytes] -> [F, H, W, 3]."""
+        torch = _torch()
+        g = gathered
+        if g.dim() != 3 or g.shape[0] != n_ranks or g.dtype != torch.uint8 or g.stride(2) != 1:
+            raise ValueError("gathered must be a uint8 [n_ranks, n_frames, slab_bytes] tensor with unit inner stride")
+        nf = g.shape[1]
+        if out is None:
+            out = self._alloc((nf, height, width, 3), torch.uint8)
+        _check_out(out, (nf, height, width, 3), torch.uint8, self.device)
+        if nf:
+            self._check(self._L.rt_scatter_rows_frames(self._h, g.data_ptr(), g.stride(0), g.stride(1), n_ranks, nf,
+                                                       width, height, tile_rows, out.data_ptr()))
+        return out
+
     def ray_counts(self) -> dict:
         """{'primary','reflection','shadow','shaded_hits','total'} since the last reset (syncs)."""
         a = (ctypes.c_uint64 * 4)()

@@ -57,3 +57,56 @@ def test_gather_row_tiles_gloo(world, w, h, tile_rows):
         assert p.exitcode == 0
     ok, nonblack, frames_ok = q.get(timeout=5)
     assert ok and frames_ok and (nonblack or h < 8)
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd.distributed import BatchExchange
+        F, nbytes, steps = 3, 40, 7
+        placed = []
+
+        def place(gathered, step):       # root only: every rank's slab of that step, in submission order
+            exp = torch.stack([torch.full((F, nbytes), (step * 16 + r) % 251, dtype=torch.uint8) for r in range(world)])
+            placed.append((step, bool(torch.equal(gathered, exp))))
+
+        ex = BatchExchange(F, nbytes, "cpu", place)
+        for i in range(steps):
+            ex.slab(i).fill_((i * 16 + rank) % 251)       # "render" this rank's tiles of batch i
+            ex.submit(i)
+        ex.drain()
+        if rank == 0:
+            q.put(placed)
+        else:
+            assert placed == []
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batch_exchange_pipeline_gloo(world):
+    """bench.py's N > 1 loop: double-buffered gather of frame batches overlapped with the next render."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    placed = q.get(timeout=5)
+    assert [s for s, _ in placed] == list(range(7)) and all(ok for _, ok in placed)
+
+
+def test_batch_exchange_single_process():
+    from raytracer_amd.distributed import BatchExchange
+    seen = []
+    ex = BatchExchange(2, 8, "cpu", lambda g, i: seen.append((i, g.shape, int(g[0, 0, 0]))))
+    for i in range(3):
+        ex.slab(i).fill_(i + 1)
+        ex.submit(i)
+    ex.drain()
+    assert seen == [(0, (1, 2, 8), 1), (1, (1, 2, 8), 2), (2, (1, 2, 8), 3)]

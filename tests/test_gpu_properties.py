@@ -281,3 +281,13 @@ def test_batched_row_tiles_with_frame_stride(renderer):
         img = renderer.scatter_rows(gathered[:, f], G, w, h, tr)
         assert torch.equal(img, full[f])
         assert torch.equal(img, renderer.render(w, h, 1, camera=cams[f], seed=f))
+    # the whole batch in one launch (rt_scatter_rows_frames), also with an odd width (byte path)
+    assert torch.equal(renderer.scatter_rows_frames(gathered, G, w, h, tr), full)
+    w2 = 333
+    full2 = renderer.render_frames(cams[:5], list(range(5)), w2, h, 1)
+    g2 = torch.zeros((G, 5, rows_max * w2 * 3), dtype=torch.uint8, device="cuda:0")
+    for r in range(G):
+        renderer.render_frames(cams[:5], list(range(5)), w2, h, 1, out=g2[r].view(5, rows_max, w2, 3),
+                               tile_rows=tr, tile_first=r, tile_stride=G)
+    assert torch.equal(renderer.scatter_rows_frames(g2, G, w2, h, tr), full2)
+
