@@ -2,14 +2,16 @@
 // aram-ap/RayTracer (raytracer.py:93-104, 139-140, 152-211, 232-260, 289-325).
 //
 // This is not a translation of the reference's Python:
-//   * recursion -> iterative throughput accumulator, and further -> a workgroup-level work queue
-//     in LDS: primary hits and reflected hits are compacted into dense batches, so the shadow-ray
-//     loop (13 of every 14 rays) runs with full 64-lane waves whatever the hit pattern;
-//   * the 13 shadow rays of one shading point are traced together against each sphere (shared
-//     origin => shared `C - O`, sqrt-free any-hit test, branch-free min/max accumulation);
-//   * sphere geometry is staged once per workgroup into LDS and read back as wave-uniform
-//     broadcasts; finished pixels are staged in LDS and leave as whole-dword packed-RGB stores;
-//   * up to 16 frames go in one launch so small frames still fill 256 CUs.
+//   * primary rays and shading are two kernels: a visibility pass (four pixels per lane, per-wave
+//     sphere culling for large scenes) writes per-tile hit indices and occupancy bits; persistent
+//     waves then shade — recursion became an iterative throughput accumulator, and further per-wave
+//     work lists in LDS: primary hits and reflected hits are compacted into dense 64-lane passes,
+//     so the shadow-ray loop (13 of every 14 rays) runs with full waves whatever the hit pattern;
+//   * the 13 shadow rays of one shading point are traced together (shared origin => shared
+//     `C - O`, sqrt-free any-hit test, sign-bit verdicts), and only against the few spheres that a
+//     per-object table (FP64, scene upload) and a per-point cone test leave as candidates;
+//   * sphere geometry is staged once per workgroup into LDS; up to 64 frames share one launch pair
+//     so that the persistent kernel's fixed cost is paid once.
 // DESIGN.md describes the layout and the roofline; include/rt355.h documents the ABI.
 #include <hip/hip_runtime.h>
 
