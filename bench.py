@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+MEASURED_TRAFFIC_C2 = 1.92e9        # bytes per 64-frame launch pair, profiles/r1j_c2_* (see roofline.traffic)
 PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 core (cannot run here)
 
 WORKLOADS = {
@@ -225,7 +226,13 @@ def main():
             "rays_per_pixel": total_rays / max(primary, 1.0),
             "mpixels_per_s": primary / dt / 1e6,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         # HBM bytes per launch pair: a separate rocprofv3 --pmc pass of this same command
+                         # (tools/profile.sh; TCC_EA0_WRREQ_sum x 64 B + TCC_EA0_RDREQ_sum x 64 B x 2, the
+                         # gfx950 correction of MI355X_MICROARCH.md), profiles/r1j_c2_*: visibility 7.2e8 W,
+                         # stream 1.07e9 W + 1.2e8 R.  Known for the default workload only.
+                         "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 64 and args.samples == 1
+                                                            and world == 1 and args.kernel == "stream") else None,
                          "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
                                     "also cover the ~4 us rt_camera_table_kernel and a 0.26 MB memset)")
                          if args.kernel == "stream" else "rt_pixel_kernel", "kernel_ms": kern_ms,
