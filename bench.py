@@ -156,6 +156,7 @@ def main():
 
     from raytracer_amd.scenes import Camera
     cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
+    cams = r.pack_cameras(cams)                 # packed once: the step loop must not be host-bound at N = 8
 
     def step(i, timed_idx=None):
         # N = 1: the rank owns every row, so its packed slab IS the frame batch

@@ -150,6 +150,19 @@ class Renderer:
                                                 _lib.RNG_MODES[rng_mode], int(seed), out.data_ptr()))
         return out
 
+    @staticmethod
+    def pack_cameras(cameras):
+        """Cameras -> the rt_camera array render_frames hands to the library.  Animation loops that reuse
+        their cameras can pack them once and pass the result instead of the list."""
+        packed = {}
+        items = []
+        for c in cameras:
+            k = id(c)
+            if k not in packed:
+                packed[k] = RtCamera.from_camera(c)
+            items.append(packed[k])
+        return (RtCamera * len(items))(*items)
+
     def render_frames(self, cameras, seeds, width, height, samples=1, *,
                       max_depth=_DEFAULT_MAX_DEPTH, rng_mode="keyed", out=None,
                       tile_rows=None, tile_first=0, tile_stride=1):
@@ -173,7 +186,7 @@ class Renderer:
             raise ValueError(f"out must be [n_frames, >= {rows}, {width}, 3]")
         _check_out(out, (n, out.shape[1], width, 3), torch.uint8, self.device)
         stride_px = out.shape[1] * width
-        cams = (RtCamera * max(n, 1))(*[RtCamera.from_camera(c) for c in cameras])
+        cams = cameras if isinstance(cameras, ctypes.Array) else self.pack_cameras(cameras)
         sd = (ctypes.c_uint64 * max(n, 1))(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds])
         if n and width * rows:
             nrows = ctypes.c_int(0)
