@@ -1880,7 +1880,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const long long frame_px = out_frame_stride_px ? out_frame_stride_px : win_px;
 
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  const int batch = std::min(n_frames, kMaxBatch);
+  // frames per launch pair: at most RT_FRAMES_PER_LAUNCH, and few enough that tile ids stay below 2^30
+  // (the kernels count tiles of a batch in 32-bit integers)
+  const long long frame_tiles = (long long)((w.nx + 7) / 8) * ((w.n_rows + 7) / 8);
+  const int max_batch = int(std::max<long long>(1, std::min<long long>(kMaxBatch, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
+  const int batch = std::min(n_frames, max_batch);
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
   const bool cubes = ctx->n_cubes > 0;
   if ((refr || cubes) && ctx->kernel != RT_KERNEL_STREAM)
@@ -1956,8 +1960,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   }
   const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr) : pixel_lds(ctx->n_spheres);
 
-  for (int f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
-    const int nf = std::min(kMaxBatch, n_frames - f0);
+  for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
+    const int nf = std::min(max_batch, n_frames - f0);
     p.n_frames = nf;
     for (int f = 0; f < nf; ++f) {
       p.cams[f] = cams[f0 + f];
