@@ -40,6 +40,7 @@ WORKLOADS = {
     "c2": (1920, 1080, 8, 1, True, 5, "config 2: 1920x1080, 8-sphere scene, depth 5, shadow rays"),
     "t64": (1920, 1080, 64, 2, False, 5, "north-star target: 1920x1080, 64 spheres, depth 5"),
     "c3": (3840, 2160, 64, 2, False, 8, "config 3: 3840x2160, 64 spheres, depth 8"),
+    "c5": (1920, 1080, 8, 1, True, 5, "config 5: 1080p camera-orbit animation over config 2's scene (use --frames 256)"),
     # SURVEY.md 8(f) rows measured beside the headline (not bench lines of BASELINE.json)
     "refr": (1920, 1080, 5, 0, True, 5, "8f rank 2: refractive_scene() (default scene + glass) 1920x1080 depth 5"),
     "cubes": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene() (default scene + 3 opaque cubes) 1920x1080 depth 5"),
@@ -156,6 +157,9 @@ def main():
 
     from raytracer_amd.scenes import Camera
     cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
+    if args.workload == "c5":                   # BASELINE config 5: frame f of a 256-frame orbit
+        from raytracer_amd.scenes import orbit_camera
+        cams = [orbit_camera(f % 256, 256) for f in range(F)]
     cams = r.pack_cameras(cams)                 # packed once: the step loop must not be host-bound at N = 8
 
     def step(i, timed_idx=None):
@@ -226,6 +230,7 @@ def main():
             "rays_per_frame": total_rays / (args.steps * F),
             "rays_per_pixel": total_rays / max(primary, 1.0),
             "mpixels_per_s": primary / dt / 1e6,
+            "frames_per_s": args.steps * F / dt,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          # HBM bytes per launch pair: a separate rocprofv3 --pmc pass of this same command
