@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=64, help="frames per step (batch)")
+    ap.add_argument("--frames", type=int, default=256, help="frames per step (batch)")
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--kernel", default="stream", choices=["stream", "pixel"])
@@ -237,7 +237,7 @@ def main():
                          # (tools/profile.sh; TCC_EA0_WRREQ_sum x 64 B + TCC_EA0_RDREQ_sum x 64 B x 2, the
                          # gfx950 correction of MI355X_MICROARCH.md), profiles/r1j_c2_*: visibility 7.2e8 W,
                          # stream 1.07e9 W + 1.2e8 R.  Known for the default workload only.
-                         "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 64 and args.samples == 1
+                         "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 256 and args.samples == 1
                                                             and world == 1 and args.kernel == "stream") else None,
                          "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
                                     "also cover the ~4 us rt_camera_table_kernel and a 0.26 MB memset)")

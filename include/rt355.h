@@ -28,7 +28,7 @@ extern "C" {
 #define RT_MAX_SPHERES 2048      /* 16 B of LDS per sphere in the shading kernels: 32 KiB      */
 #define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
 #define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
-#define RT_FRAMES_PER_LAUNCH 64  /* frames of a batch that share one kernel launch pair        */
+#define RT_FRAMES_PER_LAUNCH 256 /* frames of a batch that share one kernel launch pair        */
 
 #define RT_OK 0
 #define RT_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned)          */

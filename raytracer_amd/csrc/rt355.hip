@@ -67,6 +67,21 @@ struct DevLights {
 // gaps between dependent launches: ~0.1 ms) is paid once per batch — 16 -> 64 frames is +14 % on config 2
 constexpr int kMaxBatch = RT_FRAMES_PER_LAUNCH;
 struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
+static_assert(kMaxBatch <= 256, "frame numbers travel in 8 bits of the work-list records");
+
+// Per-frame inputs of a batch.  A launch's kernel arguments are limited to 4 KB, so the cameras of up to
+// 256 frames live in device memory: rt_store_frames_kernel writes them there from kernel arguments,
+// 64 frames per (tiny) launch — no host-to-device copy, so the host never waits for the stream.
+struct __attribute__((aligned(64))) FrameRec {
+  rt_camera cam;
+  uint32_t seed;
+  uint32_t pad[3];
+};
+constexpr int kFrameChunk = 64;
+struct FrameChunk {
+  rt_camera cam[kFrameChunk];
+  uint32_t seed[kFrameChunk];
+};
 
 struct RenderParams {
   DevLights L;
@@ -106,8 +121,7 @@ struct RenderParams {
   unsigned long long* counters;  // [kCounterSlots][8]
   long long frame_stride_px;     // pixels between frames in out_*
   long long accum_stride_px;     // pixels between frames in accum
-  rt_camera cams[kMaxBatch];
-  uint32_t seeds[kMaxBatch];
+  const FrameRec* frames;  // [n_frames] camera and folded seed of each frame of the batch (device; rt_store_frames_kernel)
 };
 
 #ifndef RT_VIS_TILES
@@ -367,6 +381,13 @@ __device__ __forceinline__ void surface_normal(const float4* __restrict__ sg, in
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+typedef const FrameRec __attribute__((address_space(4))) * cframe_t;
+__device__ __forceinline__ cframe_t as_const(const FrameRec* p) { return (cframe_t)(unsigned long long)(p); }
+#else
+typedef const FrameRec* cframe_t;
+__device__ __forceinline__ cframe_t as_const(const FrameRec* p) { return p; }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 typedef const uint32_t __attribute__((address_space(4))) * cocc_t;
 __device__ __forceinline__ cocc_t as_const(const uint32_t* p) { return (cocc_t)(unsigned long long)(p); }
 #else
@@ -518,11 +539,19 @@ __device__ __forceinline__ void primary_hit(const float4* __restrict__ gg, const
 // same stream): per sphere C - O and -(c - margin), c = |C - O|^2 - r^2 in FP64.  The margin
 // (2^-17 |C - O|^2, ~30x the FP32 error of nb^2 - c) makes the cheap test a superset of the exact
 // one; spheres that contain the camera can never be hit from it (near root < 0, :102) -> -inf.
-struct CamBatch {
-  float origin[kMaxBatch][3];
-};
+__global__ __launch_bounds__(256) void rt_store_frames_kernel(const FrameChunk chunk, FrameRec* __restrict__ dst, int n) {
+  const int i = threadIdx.x;
+  if (i < n) {
+    FrameRec r;
+    r.cam = chunk.cam[i];
+    r.seed = chunk.seed[i];
+    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    dst[i] = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void rt_camera_table_kernel(const float4* __restrict__ geom, int n,
-                                                              const CamBatch cb,
+                                                              const FrameRec* __restrict__ frames,
                                                               CamGroup* __restrict__ camtab, int n_frames) {
   const int n4 = cam_groups_stride(n) * 4;   // every entry of the padded table is written
   const int frame = blockIdx.y;
@@ -531,8 +560,9 @@ __global__ __launch_bounds__(256) void rt_camera_table_kernel(const float4* __re
   float ex = 0.f, ey = 0.f, ez = 0.f, ew = -INFINITY;
   if (i < n) {
     const float4 g = geom[i];
-    const double cx = double(g.x) - double(cb.origin[frame][0]), cy = double(g.y) - double(cb.origin[frame][1]),
-                 cz = double(g.z) - double(cb.origin[frame][2]);
+    const float* origin = frames[frame].cam.origin;
+    const double cx = double(g.x) - double(origin[0]), cy = double(g.y) - double(origin[1]),
+                 cz = double(g.z) - double(origin[2]);
     const double d2 = cx * cx + cy * cy + cz * cz;
     const double c = d2 - double(g.w);
     ex = float(cx); ey = float(cy); ez = float(cz);
@@ -986,13 +1016,14 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   float4 first_sphere = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cull) first_sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
   if (live[0] || cull) {                                  // (a later tile's pixel is live only if the first one's is;
-    const rt_camera& cam = p.cams[frame];                 //  with the cull all lanes take part in its ballots)
+    const FrameRec fr = as_const(p.frames)[frame];        //  with the cull all lanes take part in its ballots)
+    const rt_camera& cam = fr.cam;
     const int y = tile_rows_uniform(p) ? tile_row_base(p, row0) + ly : row_of(p, row0 + ly);
     float dx[NT], dy[NT], dz[NT], t[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       uint32_t pixel_key;
-      primary_ray<MODE>(p, cam, p.seeds[frame], p.x0 + col0 + 8 * q + lx, y, p.sample_index, pixel_key, dx[q], dy[q],
+      primary_ray<MODE>(p, cam, fr.seed, p.x0 + col0 + 8 * q + lx, y, p.sample_index, pixel_key, dx[q], dy[q],
                         dz[q]);
     }
     const CamGroup* table = p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres);
@@ -1199,8 +1230,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   if constexpr (CUBES)
     for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
-  for (int i = tid; i < kMaxBatch * 12; i += kBlock) s_cams[i] = (&p.cams[0].origin[0])[i];
-  if (tid < kMaxBatch) s_seeds[tid] = p.seeds[tid];
+  for (int i = tid; i < p.n_frames * 16; i += kBlock) {   // FrameRec = 12 camera floats, seed, 3 pad words
+    const uint32_t v = reinterpret_cast<const uint32_t*>(p.frames)[i];
+    const int f = i >> 4, k = i & 15;
+    if (k < 12) s_cams[f * 12 + k] = __uint_as_float(v);
+    else if (k == 12) s_seeds[f] = v;
+  }
   __syncthreads();   // the only workgroup-wide synchronisation
 
   const int tiles_per_frame = p.tiles8_x * p.tiles8_y;
@@ -1631,8 +1666,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_pixel_kernel(con
   const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
   const int col0 = tile_x * kTileW, row0 = tile_y * kTileH;
   const int cols = min(kTileW, p.nx - col0), rows = min(kTileH, p.n_rows - row0);
-  const rt_camera& cam = p.cams[frame];
-  const uint32_t seed32 = p.seeds[frame];
+  const rt_camera& cam = p.frames[frame].cam;
+  const uint32_t seed32 = p.frames[frame].seed;
   const long long frame_px = (long long)frame * p.frame_stride_px;
   const long long accum_px = (long long)frame * p.accum_stride_px;
 
@@ -1739,6 +1774,7 @@ struct rt_ctx {
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
   unsigned long long* d_counters = nullptr;
+  FrameRec* d_frames = nullptr;  // [kMaxBatch] cameras and seeds of the batch in flight
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
   int* d_chunk = nullptr;        // stream kernel's tile counters (kTileCounters, one per 128-byte line), followed
@@ -1963,21 +1999,27 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
     p.n_frames = nf;
-    for (int f = 0; f < nf; ++f) {
-      p.cams[f] = cams[f0 + f];
-      p.seeds[f] = uint32_t(seeds[f0 + f] ^ (seeds[f0 + f] >> 32));
+    p.frames = ctx->d_frames;
+    for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
+      FrameChunk chunk;                              // protects the previous batch's readers)
+      const int nc = std::min(kFrameChunk, nf - c0);
+      for (int f = 0; f < nc; ++f) {
+        chunk.cam[f] = cams[f0 + c0 + f];
+        chunk.seed[f] = uint32_t(seeds[f0 + c0 + f] ^ (seeds[f0 + c0 + f] >> 32));
+      }
+      for (int f = nc; f < kFrameChunk; ++f) { chunk.cam[f] = chunk.cam[0]; chunk.seed[f] = 0u; }
+      hipLaunchKernelGGL(rt_store_frames_kernel, dim3(1), dim3(256), 0, ctx->stream, chunk, ctx->d_frames + c0, nc);
+      RT_HIP(ctx, hipGetLastError());
     }
     p.out_rgb = out_rgb ? out_rgb + size_t(f0) * frame_px * 3 : nullptr;
     p.out_f32 = out_f32 ? out_f32 + size_t(f0) * frame_px * 3 : nullptr;
     p.out_hit = out_hit ? out_hit + size_t(f0) * frame_px : nullptr;
     const dim3 grid(per_frame * unsigned(nf), 1, 1);
-    {  // primary-ray tables of this batch (stream order protects the previous batch's readers)
-      CamBatch cb;
-      for (int f = 0; f < nf; ++f) memcpy(cb.origin[f], cams[f0 + f].origin, sizeof cb.origin[f]);
+    {  // primary-ray tables of this batch
       const int n4 = cam_groups_stride(ctx->n_spheres) * 4;
       {
         hipLaunchKernelGGL(rt_camera_table_kernel, dim3(unsigned((n4 + 255) / 256), unsigned(nf), 1), dim3(256),
-                           0, ctx->stream, (const float4*)ctx->d_geom, ctx->n_spheres, cb, ctx->d_camtab, nf);
+                           0, ctx->stream, (const float4*)ctx->d_geom, ctx->n_spheres, (const FrameRec*)ctx->d_frames, ctx->d_camtab, nf);
         RT_HIP(ctx, hipGetLastError());
       }
     }
@@ -2062,6 +2104,7 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
     return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_frames, sizeof(FrameRec) * kMaxBatch)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -2094,6 +2137,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_occl) (void)hipFree(ctx->d_occl);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
+  if (ctx->d_frames) (void)hipFree(ctx->d_frames);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);
   if (ctx->d_chunk) (void)hipFree(ctx->d_chunk);

@@ -166,7 +166,7 @@ class Renderer:
     def render_frames(self, cameras, seeds, width, height, samples=1, *,
                       max_depth=_DEFAULT_MAX_DEPTH, rng_mode="keyed", out=None,
                       tile_rows=None, tile_first=0, tile_stride=1):
-        """Animation batch -> uint8 [F, H, W, 3]; up to 64 frames (RT_FRAMES_PER_LAUNCH) share one kernel launch pair.
+        """Animation batch -> uint8 [F, H, W, 3]; up to 256 frames (RT_FRAMES_PER_LAUNCH) share one kernel launch pair.
 
         With ``tile_rows`` the batch holds only this rank's row tiles of every frame
         (-> uint8 [F, local_rows, W, 3], rt_render_frames_rows)."""

@@ -66,7 +66,7 @@ def test_frames_batch_equals_single_renders(renderer):
     batch = renderer.render_frames(cams, [0, 3, 77], 640, 360, 1)
     for i, f in enumerate((0, 3, 77)):
         assert torch.equal(batch[i], renderer.render(640, 360, 1, camera=cams[i], seed=f))
-    # more frames than one launch holds (RT_FRAMES_PER_LAUNCH = 64): two launches, same frames
+    # more frames than one launch holds (RT_FRAMES_PER_LAUNCH = 256): two launches, same frames
     n = _lib.FRAMES_PER_LAUNCH + 6
     cams = [orbit_camera(f) for f in range(n)]
     batch = renderer.render_frames(cams, list(range(n)), 160, 90, 1)
