@@ -114,6 +114,8 @@ struct RenderParams {
   uint32_t* occ;           // [kTileCounters][occ_words] one bit per tile: some pixel of it hit something (zeroed per
   int occ_words;           // launch, set by the visibility pass): word h * occ_words + (slot >> 5), bit slot & 31
   int tiles8_x, tiles8_y;
+  int tile_pitch;          // tile ids per tile row: tiles8_x made odd, so that the tiles of one work counter (ids
+                           // congruent mod kTileCounters) form a lattice over the whole frame instead of a few columns
   uint8_t* out_rgb;      // [frame][n_rows][nx][3] or null
   float* out_f32;        // [frame][n_rows][nx][3] or null (render_chunk)
   int32_t* out_hit;      // [frame][n_rows][nx] or null
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   // tile-major hand-over: the 64 indices of a tile are 128 contiguous bytes; lanes outside the
   // window write -1, so the consumer needs no bounds checks ...
   // ... and a header names the tile, so a record is self-describing for whoever loads it
-  int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tiles8_x + (col0 >> 3)) * kVisTile;
+  int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tile_pitch + (col0 >> 3)) * kVisTile;
   uint8_t* out = p.out_rgb + frame_px * 3;
   const bool write_rgb = p.out_rgb && last_sample && !p.defer_output;
   const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
@@ -1107,7 +1109,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
       *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
           make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
       if (occupied) {   // tile id = slot * kTileCounters + counter (see the stream kernel's tile supply)
-        const uint32_t id = uint32_t(frame) * uint32_t(p.tiles8_x * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tiles8_x) +
+        const uint32_t id = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
                             uint32_t(col0 >> 3) + uint32_t(q);
         const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
         atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   }
   __syncthreads();   // the only workgroup-wide synchronisation
 
-  const int tiles_per_frame = p.tiles8_x * p.tiles8_y;
+  const int tiles_per_frame = p.tile_pitch * p.tiles8_y;   // tile ids, padding ids (no record, no occupancy bit) included
   const int total_tiles = tiles_per_frame * p.n_frames;
   const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kBlock / 64) + wave);
   const int n_waves = int(gridDim.x) * (kBlock / 64);
@@ -1264,7 +1266,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   // slots not yet started, and the tile id of bit 0.  Empty tiles (81 % of config 2's) are never loaded.
   uint32_t cl_mask = 0u;
   int cl_base = 0;
-  if (gwave < total_tiles) { cl_mask = 1u; cl_base = gwave; }
+  if (gwave < total_tiles) {   // (a padding id or an empty tile has no bit)
+    const int slot0 = gwave / kTileCounters;
+    cl_mask = (as_const(p.occ)[size_t(hcur) * size_t(p.occ_words) + (slot0 >> 5)] >> (slot0 & 31)) & 1u;
+    cl_base = gwave;
+  }
   bool homeless = false;           // the counter this wave drew from is exhausted: it must find another
   int pf_n = 0, pf_c = 0;          // the claim being requested (lane 0 receives the counter value)
   bool nx_valid = false;           // the claim after the current one: slots, first tile id, and the two
@@ -1918,7 +1924,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   RT_HIP(ctx, hipSetDevice(ctx->device));
   // frames per launch pair: at most RT_FRAMES_PER_LAUNCH, and few enough that tile ids stay below 2^30
   // (the kernels count tiles of a batch in 32-bit integers)
-  const long long frame_tiles = (long long)((w.nx + 7) / 8) * ((w.n_rows + 7) / 8);
+  const long long frame_tiles = (long long)(((w.nx + 7) / 8) | 1) * ((w.n_rows + 7) / 8);   // tile ids per frame (odd pitch)
   const int max_batch = int(std::max<long long>(1, std::min<long long>(kMaxBatch, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
   const int batch = std::min(n_frames, max_batch);
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
@@ -1938,7 +1944,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   if (stream_kernel) {  // primary-hit indices handed from the visibility pass to the stream kernel
-    const size_t need = size_t((w.nx + 7) / 8) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles
+    const size_t need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles, odd pitch
     if (need > ctx->vis_elems) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_vis) RT_HIP(ctx, hipFree(ctx->d_vis));
@@ -1967,7 +1973,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.vis = ctx->d_vis;
   // tile occupancy: per counter one bit per slot, rounded up to words, plus one word of padding (a claim's
   // bits are read as two words)
-  const long long batch_tiles = (long long)((w.nx + 7) / 8) * ((w.n_rows + 7) / 8) * batch;
+  const long long batch_tiles = frame_tiles * batch;
   const int occ_words = int(((batch_tiles + kTileCounters - 1) / kTileCounters + 31) / 32) + 1;
   if (stream_kernel) {
     const size_t need = size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4;
@@ -1986,7 +1992,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.counters = ctx->d_counters;
   p.frame_stride_px = frame_px;
   p.accum_stride_px = win_px;
-  p.vis_stride = (long long)p.tiles8_x * p.tiles8_y * kVisTile;
+  p.tile_pitch = p.tiles8_x | 1;
+  p.vis_stride = (long long)p.tile_pitch * p.tiles8_y * kVisTile;
   unsigned per_frame;
   if (stream_kernel) {
     p.strips_x = p.tiles8_x; p.strips_y = p.tiles8_y;   // work units of the stream kernel: 8x8 tiles
