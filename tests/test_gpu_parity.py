@@ -241,6 +241,41 @@ def test_refraction_glass_in_front_of_light_does_not_shadow(renderer, oracle):
     assert (imgs[0].sum(-1) > imgs[1].sum(-1) + 30).mean() > 0.01   # the opaque sphere's shadow is gone
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_random_lights_and_cameras_against_oracle(renderer, oracle, case):
+    """The culls of the shadow scan and of the primary scan take the light positions, the area light's
+    extent and the camera as inputs: random ones here (lights next to, inside and far from spheres,
+    extents 0.05 ... 8, 1 ... 20 samples), each frame against the oracle."""
+    from raytracer_amd.scenes import AreaLight, Light
+    rng = np.random.default_rng(100 + case)
+    n = int(rng.choice([3, 8, 20, 64, 150]))
+    sc = generate_scene(n, int(rng.integers(1, 1000)), keep_default=(n == 8))
+    sph = sc["spheres"]
+
+    def rand_pos():
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            return Vector3(rng.uniform(-15, 15), rng.uniform(-10, 15), rng.uniform(-28, 12))
+        s = sph[int(rng.integers(0, len(sph)))]
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        k = {1: 1.05, 2: 0.5, 3: 3.0}[mode]
+        return Vector3(s.center.x + d[0] * s.radius * k, s.center.y + d[1] * s.radius * k, s.center.z + d[2] * s.radius * k)
+
+    sc["global_light"] = Light(rand_pos(), Vector3(1, 1, 1), 0.9)
+    ext = float(rng.choice([0.05, 0.5, 1.0, 3.0, 8.0]))
+    u = rng.normal(size=3); v = rng.normal(size=3)
+    u = u / np.linalg.norm(u) * ext; v = v / np.linalg.norm(v) * ext * rng.uniform(0.2, 1)
+    sc["area_light"] = AreaLight(rand_pos(), Vector3(*u), Vector3(*v), Vector3(1, 1, 1), 0.9,
+                                 samples=int(rng.choice([1, 4, 12, 20])))
+    cam = None if case % 3 == 0 else orbit_camera(int(rng.integers(0, 256)), 256, radius=float(rng.uniform(3, 12)))
+    w, h, D = 320, 180, int(rng.integers(0, 7))
+    renderer.upload_scene(sc)
+    img, hit = renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True)
+    o = oracle.render_scene(sc, w, h, max_depth=D, mode="K", seed=case, camera=cam)
+    check_hits(hit.cpu().numpy(), o["hit"], o["margin"])
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+
+
 def check_cube_hits(gpu_hit, o):
     """Primary hit index with cubes in the list: the oracle's margin only knows sphere silhouettes, so
     mismatches are bounded in number (edges of a box are one pixel wide) instead of classified."""

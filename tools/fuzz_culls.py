@@ -1,0 +1,44 @@
+"""GPU box: randomized check that none of the culls changes a byte.  Random scenes (sphere count, light
+positions and sizes — also lights next to or inside spheres —, cameras); each is rendered by the default
+path with the occluder table on and off and by the one-thread-per-pixel kernel (linear primary scan,
+same shading): frames and hit maps must be identical."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from raytracer_amd.render import Renderer
+from raytracer_amd.scenes import AreaLight, Camera, Light, Vector3, generate_scene, orbit_camera
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+r = Renderer(0)
+bad = 0
+for case in range(n_cases):
+    n = int(rng.choice([3, 8, 20, 64, 150, 400]))
+    sc = generate_scene(n, int(rng.integers(1, 1000)), keep_default=bool(rng.integers(0, 2)) and n >= 3)
+    sph = sc["spheres"]
+    def rand_pos():
+        mode = rng.integers(0, 4)
+        if mode == 0:   # somewhere around the scene
+            return Vector3(*(rng.uniform(-15, 15), rng.uniform(-10, 15), rng.uniform(-28, 12)))
+        s = sph[int(rng.integers(0, len(sph)))]
+        c = np.array([s.center.x, s.center.y, s.center.z]); d = rng.normal(size=3); d /= np.linalg.norm(d)
+        k = {1: 1.05, 2: 0.5, 3: 3.0}[int(mode)]     # just outside, inside, a few radii away from a sphere
+        return Vector3(*(c + d * s.radius * k))
+    sc["global_light"] = Light(rand_pos(), Vector3(1, 1, 1), 0.9)
+    ext = float(rng.choice([0.05, 0.5, 1.0, 3.0, 8.0]))
+    u = rng.normal(size=3); v = rng.normal(size=3)
+    sc["area_light"] = AreaLight(rand_pos(), Vector3(*(u / np.linalg.norm(u) * ext)), Vector3(*(v / np.linalg.norm(v) * ext * rng.uniform(0.2, 1))),
+                                 Vector3(1, 1, 1), 0.9, samples=int(rng.choice([1, 4, 12, 20])))
+    cam = None if rng.integers(0, 3) == 0 else orbit_camera(int(rng.integers(0, 256)), 256, radius=float(rng.uniform(3, 12)))
+    w, h, D = int(rng.integers(100, 500)), int(rng.integers(60, 300)), int(rng.integers(0, 7))
+    outs = []
+    for table, kernel in ((True, "stream"), (False, "stream"), (True, "pixel")):
+        r.set_occluder_table(table); r.set_kernel(kernel); r.upload_scene(sc)
+        outs.append(r.render(w, h, 1, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True))
+    r.set_kernel("stream"); r.set_occluder_table(True)
+    same = all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    lit = float((outs[0][0].max(-1).values > 0).float().mean())
+    print(f"case {case}: n={n} {w}x{h} D={D} ext={ext} ns={sc['area_light'].samples} lit={lit:.3f} {'ok' if same else 'DIFFERENT'}", flush=True)
+    bad += not same
+print("fuzz: all identical" if bad == 0 else f"fuzz: {bad} cases differ")
+sys.exit(1 if bad else 0)
