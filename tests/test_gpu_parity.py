@@ -276,6 +276,39 @@ def test_random_lights_and_cameras_against_oracle(renderer, oracle, case):
     check_rgb(img.cpu().numpy(), o["rgb8"])
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_random_glass_and_cubes_against_oracle(renderer, oracle, case):
+    """Random mixes of opaque / glass spheres and small cubes (the REFR and CUBES kernel variants, the
+    bounded bounce queue) against the oracle."""
+    rng = np.random.default_rng(500 + case)
+    n = int(rng.choice([4, 8, 16]))
+    sc = generate_scene(n, int(rng.integers(1, 1000)), keep_default=(n == 8))
+    objs = list(sc["spheres"])
+    for s_ in objs:
+        if rng.random() < (0.0 if case % 4 == 3 else 0.35):      # (every fourth case: cubes only, opaque path)
+            s_.material.refraction = float(rng.uniform(0.2, 0.9))
+            s_.material.refractive_index = float(rng.choice([0.8, 1.0, 1.33, 1.5]))
+        if rng.random() < 0.3:
+            s_.material.reflection = 0.0
+    for _ in range(int(rng.integers(0, 4))):
+        c = np.array([rng.uniform(-4, 4), rng.uniform(-2.5, 2.5), rng.uniform(-14, -3)])
+        e = rng.uniform(0.15, 0.6, 3)
+        m = Material(Vector3(*rng.uniform(0.3, 1, 3)), specular=float(rng.uniform(0, 1)), reflection=float(rng.choice([0, 0.3, 0.6])),
+                     refraction=float(rng.choice([0, 0, 0.7])) if case % 4 != 3 else 0.0, refractive_index=float(rng.choice([1.0, 1.5])))
+        objs.insert(int(rng.integers(0, len(objs) + 1)), Cube(Vector3(*(c - e)), Vector3(*(c + e)), m))
+    sc["spheres"] = objs
+    cam = None if case % 2 == 0 else orbit_camera(int(rng.integers(0, 256)), 256, radius=float(rng.uniform(4, 9)))
+    w, h, D = 240, 135, int(rng.integers(0, 7))
+    renderer.upload_scene(sc)
+    renderer.reset_ray_counts()
+    img, hit = renderer.render(w, h, 2, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True)
+    o = oracle.render_scene(sc, w, h, samples=2, max_depth=D, mode="K", seed=case, camera=cam)
+    check_cube_hits(hit.cpu().numpy(), o)
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+    rc = renderer.ray_counts()
+    assert abs(rc["shaded_hits"] - int(o["hit_levels"].sum())) <= max(8, 3e-3 * o["hit_levels"].sum())
+
+
 def check_cube_hits(gpu_hit, o):
     """Primary hit index with cubes in the list: the oracle's margin only knows sphere silhouettes, so
     mismatches are bounded in number (edges of a box are one pixel wide) instead of classified."""
