@@ -1103,12 +1103,13 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     if (cols[q] <= 0) break;                                  // wave-uniform: this tile and the ones after it do not exist
-    rec[q * kVisTile + lane] = int16_t(idx[q]);
+    // (a tile without a hit gets no record and no occupancy bit: the stream kernel never looks at it)
     const bool occupied = __ballot(idx[q] >= 0) != 0ull;
-    if (lane == 0) {
+    if (occupied) rec[q * kVisTile + lane] = int16_t(idx[q]);
+    if (occupied && lane == 0) {
       *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
           make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
-      if (occupied) {   // tile id = slot * kTileCounters + counter (see the stream kernel's tile supply)
+      {   // tile id = slot * kTileCounters + counter (see the stream kernel's tile supply)
         const uint32_t id = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
                             uint32_t(col0 >> 3) + uint32_t(q);
         const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
