@@ -1223,10 +1223,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
   const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
-  float* s_cams = reinterpret_cast<float*>(smem + geom_bytes);                 // [kMaxBatch][12]
-  uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_cams + kMaxBatch * 12);    // [kMaxBatch]
+  float* s_cams = reinterpret_cast<float*>(smem + geom_bytes);                 // [frames of the batch][12]
+  const int frames_lds = (p.n_frames + 3) & ~3;                               // (keeps what follows 16-byte aligned)
+  uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_cams + frames_lds * 12);   // [frames_lds]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  unsigned char* mine = reinterpret_cast<unsigned char*>(s_seeds + kMaxBatch) + wave * kWaveLdsBytes;
+  unsigned char* mine = reinterpret_cast<unsigned char*>(s_seeds + frames_lds) + wave * kWaveLdsBytes;
   Queue<kCap> q{reinterpret_cast<float*>(mine)};
   uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kCap * 4);
   int16_t* ring = reinterpret_cast<int16_t*>(pend + kPendingCap);               // [kRing][kVisTile] tile records
@@ -1818,8 +1819,8 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres, bool refr = false) {
-  return geom_lds(n_spheres) + size_t(kMaxBatch) * 13 * 4 + size_t(wave_lds_bytes(refr)) * (kBlock / 64);
+size_t stream_lds(int n_spheres, bool refr = false, int n_frames = kMaxBatch) {   // cameras and seeds of the batch's frames
+  return geom_lds(n_spheres) + size_t((n_frames + 3) & ~3) * 13 * 4 + size_t(wave_lds_bytes(refr)) * (kBlock / 64);
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -2002,10 +2003,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   } else {
     per_frame = unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH);
   }
-  const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr) : pixel_lds(ctx->n_spheres);
 
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
+    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, nf) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = ctx->d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
