@@ -40,6 +40,7 @@ WORKLOADS = {
     "c2": (1920, 1080, 8, 1, True, 5, "config 2: 1920x1080, 8-sphere scene, depth 5, shadow rays"),
     "t64": (1920, 1080, 64, 2, False, 5, "north-star target: 1920x1080, 64 spheres, depth 5"),
     "c3": (3840, 2160, 64, 2, False, 8, "config 3: 3840x2160, 64 spheres, depth 8"),
+    "c4": (7680, 4320, 1024, 3, False, 5, "config 4: 7680x4320, 1024 spheres, depth 5 (use --frames 16)"),
     "c5": (1920, 1080, 8, 1, True, 5, "config 5: 1080p camera-orbit animation over config 2's scene (use --frames 256)"),
     # SURVEY.md 8(f) rows measured beside the headline (not bench lines of BASELINE.json)
     "refr": (1920, 1080, 5, 0, True, 5, "8f rank 2: refractive_scene() (default scene + glass) 1920x1080 depth 5"),
