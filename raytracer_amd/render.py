@@ -40,6 +40,8 @@ class Renderer:
         _lib.check(self._L.rt_create(self.device, ctypes.byref(h)))
         self._h = h
         self._packed: PackedScene | None = None
+        self._options = {"occluder_table": True}     # options that take effect at upload time
+        self._uploaded_options = None
         self.use_torch_stream()
 
     # -- lifetime -------------------------------------------------------------------------
@@ -70,8 +72,11 @@ class Renderer:
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))
 
-    def upload_scene(self, scn: dict | PackedScene | None = None) -> PackedScene:
+    def upload_scene(self, scn: dict | PackedScene | None = None, *, force: bool = False) -> PackedScene:
         p = scn if isinstance(scn, PackedScene) else pack_scene(scene if scn is None else scn)
+        if not force and self._packed is not None and self._uploaded_options == self._options \
+                and _same_scene(p, self._packed):
+            return self._packed          # the device already holds exactly this scene (and its occluder table)
         lights = p.ct_lights()
         g, m, s = (np.ascontiguousarray(a, np.float32) for a in (p.geom4, p.mat4, p.spec))
         self._check(self._L.rt_upload_scene(self._h, g.ctypes.data, m.ctypes.data, s.ctypes.data,
@@ -85,6 +90,7 @@ class Renderer:
                  (p.cube_box, p.cube_mat4, p.cube_spec, p.cube_refr[:, 0], p.cube_refr[:, 1])]
             self._check(self._L.rt_set_cubes(self._h, *[x.ctypes.data for x in a], p.n_cubes))
         self._packed = p
+        self._uploaded_options = dict(self._options)
         return p
 
     # -- renders --------------------------------------------------------------------------
@@ -206,6 +212,7 @@ class Renderer:
         """Shadow scan over the per-object candidate table (default) or over every sphere; same images.
         Takes effect at the next upload_scene."""
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_OCCLUDER_TABLE, 1 if on else 0))
+        self._options["occluder_table"] = bool(on)
 
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
@@ -245,6 +252,27 @@ class Renderer:
 
     def reset_ray_counts(self):
         self._check(self._L.rt_reset_ray_counts(self._h))
+
+
+def _same_scene(a: PackedScene, b: PackedScene) -> bool:
+    """Bitwise equality of everything upload_scene sends to the device."""
+    if a.area_samples != b.area_samples:
+        return False
+    for name in ("geom4", "mat4", "spec", "lights", "refr", "cube_box", "cube_mat4", "cube_spec", "cube_refr", "order"):
+        x, y = getattr(a, name), getattr(b, name)
+        if x.shape != y.shape or x.tobytes() != y.tobytes():
+            return False
+    return True
+
+
+def _to_host(t):
+    """Device tensor -> numpy array through a pinned staging buffer of its own (torch caches pinned
+    allocations; the array keeps its buffer alive): ~3x the rate of a pageable copy."""
+    torch = _torch()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
 
 
 def _dims(width, height):
@@ -290,8 +318,8 @@ def render(width, height, samples=1, *, scene=None, max_depth=_DEFAULT_MAX_DEPTH
     res = r.render(width, height, samples, max_depth=max_depth, camera=camera, rng_mode=rng_mode,
                    seed=seed, return_hit_index=return_hit_index)
     if return_hit_index:
-        return res[0].cpu().numpy(), res[1].cpu().numpy()
-    return res.cpu().numpy()
+        return _to_host(res[0]), _to_host(res[1])
+    return _to_host(res)
 
 
 def render_chunk(args, *, max_depth=_DEFAULT_MAX_DEPTH, camera=None, rng_mode="keyed", seed=0,
