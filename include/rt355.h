@@ -88,9 +88,14 @@ int rt_synchronize(rt_ctx* ctx);
  *   compute the same arithmetic per ray.
  *   RT_OPT_OCCLUDER_TABLE: 1 (default) = the shadow scan of a hit on object k only looks at the spheres
  *   that can shadow some point of k (see rt_occluder_table); 0 = at every sphere, as the reference
- *   does.  Images are byte-identical either way (tests); takes effect at the next rt_upload_scene. */
+ *   does.  Images are byte-identical either way (tests); takes effect at the next rt_upload_scene.
+ *   RT_OPT_SPHERE_GRID: 1 (default) = reflection rays of scenes with >= 128 spheres (no cubes, no
+ *   refraction) walk a uniform grid built at scene upload instead of testing every sphere; 0 = the
+ *   plain scan of find_nearest_intersection (raytracer.py:152-172).  Same images (tests); takes effect
+ *   at the next rt_upload_scene. */
 #define RT_OPT_KERNEL 1
 #define RT_OPT_OCCLUDER_TABLE 2
+#define RT_OPT_SPHERE_GRID 3
 #define RT_KERNEL_STREAM 0
 #define RT_KERNEL_PIXEL 1
 int rt_set_option(rt_ctx* ctx, int option, int value);

@@ -103,6 +103,12 @@ struct RenderParams {
   const float2* refr;    // refraction, refractive_index (raytracer.py:43); only read by the REFR kernels
   const uint32_t* occl;  // [objects][occl_words] bit c of row k: sphere c can shadow some point of object k (host table)
   int occl_words;        // ceil(n_spheres / 32)
+  // uniform grid over the spheres for reflection rays of many-sphere scenes (grid_dim = 0: none)
+  const uint32_t* grid_start;   // [grid_dim^3 + 1] first entry of each cell in grid_items
+  const uint16_t* grid_items;   // sphere indices, ascending within a cell
+  const uint16_t* grid_big;     // spheres that span too many cells: always tested
+  int grid_dim, grid_n_big;
+  float grid_min[3], grid_inv_cell[3], grid_cell[3];
   const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
   int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
@@ -228,6 +234,10 @@ __device__ __forceinline__ int tile_row_base(const RenderParams& p, int row0) {
 __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const float4* __restrict__ gg,
                                             int n, float ox, float oy, float oz, float dx, float dy,
                                             float dz, float& best_t, int& best_i) {
+  // only the fused multiply-adds written out below: the hit distance must come out the same to the
+  // last bit wherever this test is inlined (sphere_t_exact, nearest_grid), whatever the optimiser
+  // would contract in each context
+#pragma clang fp contract(off)
   const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // :95, computed, not assumed 1
   best_t = INFINITY;
   best_i = -1;
@@ -268,6 +278,7 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const
 // nearest_hit: returns t (valid iff dl >= 0 and t > 0).
 __device__ __forceinline__ float sphere_t_exact(const float4 s, float ox, float oy, float oz, float dx,
                                                 float dy, float dz, float inv_a, float& dl) {
+#pragma clang fp contract(off)
   const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
   const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
   const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
@@ -353,6 +364,77 @@ __device__ __forceinline__ void nearest_object(const float4* __restrict__ sg, co
       int face;
       if (cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], ox, oy, oz, dx, dy, dz, ix, iy, iz, t, face) && t < best_t) {
         best_t = t; best_i = n + c; best_face = face;             // :162-163
+      }
+    }
+  }
+}
+
+// find_nearest_intersection for scenes with many spheres: a uniform grid (built at scene upload) walked
+// per lane with a 3D-DDA.  Every sphere a cell lists is tested with the expressions of nearest_hit(); the
+// walk ends when the best hit lies before the exit of the current cell, or outside the grid.  Results equal
+// the plain scan's: the nearest sphere is listed in the cell that holds its hit point (cells list
+// spheres with 2 % of a cell of slack, far above the FP32 error of the walk), and ties go to the
+// lowest index explicitly, as cells are not visited in index order.  Spheres that span many cells
+// (`grid_big`) are tested up front.  Lanes walk different cells, so the wave loops until its last lane is done;
+// every turn a lane either tests one sphere or moves to the next cell.
+__device__ __forceinline__ void nearest_grid(const RenderParams& p, const float4* __restrict__ sg, float ox, float oy,
+                                             float oz, float dx, float dy, float dz, float& best_t, int& best_i) {
+  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  best_t = INFINITY;
+  best_i = -1;
+  auto test = [&](int j) {
+    float dl;
+    const float t = sphere_t_exact(sg[j], ox, oy, oz, dx, dy, dz, inv_a, dl);
+    if (dl >= 0.0f && t > 0.0f && (t < best_t || (t == best_t && j < best_i))) { best_t = t; best_i = j; }
+  };
+  for (int b = 0; b < p.grid_n_big; ++b) test(int(p.grid_big[b]));     // wave-uniform
+  const int G = p.grid_dim;
+  // reciprocal directions; a zero component becomes a huge finite slope (no 0 * inf below)
+  auto safe_inv = [](float d) { return 1.0f / (fabsf(d) < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d); };
+  const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+  const float ex = p.grid_cell[0] * float(G), ey = p.grid_cell[1] * float(G), ez = p.grid_cell[2] * float(G);
+  const float ax = (p.grid_min[0] - ox) * ix, bx = (p.grid_min[0] + ex - ox) * ix;
+  const float ay = (p.grid_min[1] - oy) * iy, by = (p.grid_min[1] + ey - oy) * iy;
+  const float az = (p.grid_min[2] - oz) * iz, bz = (p.grid_min[2] + ez - oz) * iz;
+  const float t0 = fmaxf(0.0f, fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz))));
+  const float t1 = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+  bool active = t0 <= t1;                     // the ray touches the grid's box
+  const float sx0 = fmaf(dx, t0, ox), sy0 = fmaf(dy, t0, oy), sz0 = fmaf(dz, t0, oz);
+  int cx = min(G - 1, max(0, int((sx0 - p.grid_min[0]) * p.grid_inv_cell[0])));
+  int cy = min(G - 1, max(0, int((sy0 - p.grid_min[1]) * p.grid_inv_cell[1])));
+  int cz = min(G - 1, max(0, int((sz0 - p.grid_min[2]) * p.grid_inv_cell[2])));
+  const int stx = dx < 0.0f ? -1 : 1, sty = dy < 0.0f ? -1 : 1, stz = dz < 0.0f ? -1 : 1;
+  // ray parameter at which the walk leaves the current cell along each axis, and its step per cell
+  float tmx = (p.grid_min[0] + float(cx + (stx > 0 ? 1 : 0)) * p.grid_cell[0] - ox) * ix;
+  float tmy = (p.grid_min[1] + float(cy + (sty > 0 ? 1 : 0)) * p.grid_cell[1] - oy) * iy;
+  float tmz = (p.grid_min[2] + float(cz + (stz > 0 ? 1 : 0)) * p.grid_cell[2] - oz) * iz;
+  const float tdx = p.grid_cell[0] * fabsf(ix), tdy = p.grid_cell[1] * fabsf(iy), tdz = p.grid_cell[2] * fabsf(iz);
+  uint32_t cur = 0u, end = 0u;
+  if (active) {
+    const int cell = (cz * G + cy) * G + cx;
+    cur = p.grid_start[cell]; end = p.grid_start[cell + 1];
+  }
+  int guard = 3 * G + 8;                      // cells a walk can visit at most (a safety net: the walk ends by itself)
+  while (__ballot(active) != 0ull) {
+    if (active) {
+      if (cur < end) {
+        test(int(p.grid_items[cur]));
+        ++cur;
+      } else {
+        const float t_exit = fminf(tmx, fminf(tmy, tmz));
+        if (best_t <= t_exit || --guard < 0) {
+          active = false;                     // nothing nearer can follow
+        } else {
+          if (tmx <= tmy && tmx <= tmz) { cx += stx; tmx += tdx; }
+          else if (tmy <= tmz) { cy += sty; tmy += tdy; }
+          else { cz += stz; tmz += tdz; }
+          if (uint32_t(cx) >= uint32_t(G) || uint32_t(cy) >= uint32_t(G) || uint32_t(cz) >= uint32_t(G)) {
+            active = false;                   // left the grid
+          } else {
+            const int cell = (cz * G + cy) * G + cx;
+            cur = p.grid_start[cell]; end = p.grid_start[cell + 1];
+          }
+        }
       }
     }
   }
@@ -1216,8 +1298,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // set b
   return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
 
-template <int MODE, bool REFR, bool CUBES>
+template <int MODE, bool REFR, bool CUBES, bool GRID = false>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams p) {
+  static_assert(!GRID || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
   constexpr int kWaveLdsBytes = wave_lds_bytes(REFR);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1592,7 +1675,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           float t;
           int idx2, face;
           ++n_trace;
-          nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, dx, dy, dz, t, idx2, face);
+          if constexpr (GRID) { nearest_grid(p, sg, ox, oy, oz, dx, dy, dz, t, idx2); face = 0; }
+          else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, dx, dy, dz, t, idx2, face);
           if (idx2 >= 0) {
             again = true;
             hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, dx, dy, dz, t, px, py, pz);
@@ -1778,6 +1862,12 @@ struct rt_ctx {
   float2* d_refr = nullptr;      // refraction, refractive_index per object (rt_set_refraction, rt_set_cubes)
   bool has_refr = false;         // some sphere has refraction > 0: the REFR kernels run
   bool has_refr_cubes = false;   // some cube has
+  uint32_t* d_grid_start = nullptr;   // sphere grid of many-sphere scenes (build_sphere_grid)
+  uint16_t* d_grid_items = nullptr;
+  uint16_t* d_grid_big = nullptr;
+  int grid_dim = 0, grid_n_big = 0;
+  float grid_min[3] = {0, 0, 0}, grid_inv_cell[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0};
+  bool sphere_grid = true;            // RT_OPT_SPHERE_GRID
   uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
@@ -1838,6 +1928,71 @@ struct Window {
   int x0, nx, n_rows, tile_rows, tile_first, tile_stride, y0;
 };
 
+// Uniform grid for nearest_grid(): G^3 cells over the bounding box of the spheres, G ~ cbrt(4 n).  A cell
+// lists every sphere whose bounding box, grown by 2 % of a cell, touches it (ascending indices); spheres
+// that would be listed in more than kGridMaxCellsPerSphere cells go to `big` instead.
+constexpr int kGridFrom = 128;                 // scenes with at least this many spheres get a grid
+constexpr int kGridMaxDim = 32;
+constexpr int kGridMaxCellsPerSphere = 64;
+struct SphereGrid {
+  int dim = 0;
+  float mn[3], inv_cell[3], cell[3];
+  std::vector<uint32_t> start;
+  std::vector<uint16_t> items, big;
+};
+void build_sphere_grid(const float* geom4, int n, SphereGrid& g) {
+  g = SphereGrid();
+  if (n < kGridFrom) return;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = 0; i < n; ++i) {
+    const double r = std::sqrt(double(geom4[4 * i + 3]));
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::min(lo[k], double(geom4[4 * i + k]) - r);
+      hi[k] = std::max(hi[k], double(geom4[4 * i + k]) + r);
+    }
+  }
+  const int G = std::max(4, std::min(kGridMaxDim, int(std::cbrt(4.0 * n) + 0.5)));
+  double cell[3];
+  for (int k = 0; k < 3; ++k) {
+    const double pad = 1e-3 * (hi[k] - lo[k]) + 1e-3;
+    lo[k] -= pad; hi[k] += pad;
+    cell[k] = (hi[k] - lo[k]) / G;
+    g.mn[k] = float(lo[k]); g.cell[k] = float(cell[k]); g.inv_cell[k] = float(1.0 / cell[k]);
+  }
+  auto range = [&](int i, int k, int& a, int& b) {
+    const double r = std::sqrt(double(geom4[4 * i + 3])) * 1.0001 + 0.02 * cell[k];
+    a = std::max(0, std::min(G - 1, int(std::floor((double(geom4[4 * i + k]) - r - lo[k]) / cell[k]))));
+    b = std::max(0, std::min(G - 1, int(std::floor((double(geom4[4 * i + k]) + r - lo[k]) / cell[k]))));
+  };
+  std::vector<uint32_t> count(size_t(G) * G * G + 1, 0u);
+  std::vector<char> is_big(size_t(n), 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < n; ++i) {
+      int a[3], b[3];
+      for (int k = 0; k < 3; ++k) range(i, k, a[k], b[k]);
+      if (pass == 0) {
+        const long long cells = (long long)(b[0] - a[0] + 1) * (b[1] - a[1] + 1) * (b[2] - a[2] + 1);
+        if (cells > kGridMaxCellsPerSphere) { is_big[size_t(i)] = 1; g.big.push_back(uint16_t(i)); continue; }
+      } else if (is_big[size_t(i)]) {
+        continue;
+      }
+      for (int z = a[2]; z <= b[2]; ++z)
+        for (int y = a[1]; y <= b[1]; ++y)
+          for (int x = a[0]; x <= b[0]; ++x) {
+            const size_t c = (size_t(z) * G + y) * G + x;
+            if (pass == 0) ++count[c + 1];
+            else g.items[count[c]++] = uint16_t(i);
+          }
+    }
+    if (pass == 0) {
+      for (size_t c = 1; c < count.size(); ++c) count[c] += count[c - 1];
+      g.start = count;                         // start[c] = first entry of cell c, start[G^3] = entries
+      g.items.assign(size_t(count.back()), 0);
+    }
+  }
+  g.dim = G;
+}
+
 // Occluder table for lighting()'s shadow scan: bit c of row k says that sphere c can be hit by SOME
 // shadow ray that leaves sphere k (raytracer.py:184, :199: origins lie 0.001 off its surface) towards
 // the point light or any point of the area light.  All such rays start inside the ball (K, rho) and
@@ -1886,7 +2041,10 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes) {
   if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true> : rt_visibility_kernel<RT_RNG_KEYED, false>;
   return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false>;
 }
-RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes) {
+RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false) {
+  if (grid && !refr && !cubes)
+    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true>
+                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true>;
   if (rng_mode == RT_RNG_KEYED) {
     if (refr) return cubes ? rt_stream_kernel<RT_RNG_KEYED, true, true> : rt_stream_kernel<RT_RNG_KEYED, true, false>;
     return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true> : rt_stream_kernel<RT_RNG_KEYED, false, false>;
@@ -1969,6 +2127,12 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
   p.cubes = ctx->d_cubes; p.n_cubes = ctx->n_cubes;
   p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32;
+  p.grid_start = ctx->d_grid_start; p.grid_items = ctx->d_grid_items; p.grid_big = ctx->d_grid_big;
+  p.grid_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->grid_dim;
+  p.grid_n_big = ctx->grid_n_big;
+  for (int k = 0; k < 3; ++k) {
+    p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];
+  }
   p.defer_output = refr ? 1 : 0;
   p.accum = ctx->d_accum;
   p.camtab = ctx->d_camtab;
@@ -2049,7 +2213,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4,
                                    ctx->stream));
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes), vgrid, dim3(kBlock), vlds, ctx->stream, p);
-        hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes), sgrid, dim3(kBlock), lds, ctx->stream, p);
+        hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples)
           hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
                              ctx->stream, p);
@@ -2111,6 +2275,10 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_refr, sizeof(float2) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_grid_start, sizeof(uint32_t) * (kGridMaxDim * kGridMaxDim * kGridMaxDim + 1))) != hipSuccess ||
+      (e = hipMalloc(&ctx->d_grid_items, sizeof(uint16_t) * size_t(kGridMaxCellsPerSphere) * RT_MAX_SPHERES)) != hipSuccess ||
+      (e = hipMalloc(&ctx->d_grid_big, sizeof(uint16_t) * RT_MAX_SPHERES)) != hipSuccess)
+    return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_frames, sizeof(FrameRec) * kMaxBatch)) != hipSuccess) return bail(e, "hipMalloc");
@@ -2127,6 +2295,9 @@ int rt_create(int device_id, rt_ctx** out) {
       for (int c = 0; c < 2; ++c)
         if ((e = allow_big_lds(pick_stream_kernel(mode, r != 0, c != 0), r ? bigr : big)) != hipSuccess)
           return bail(e, "hipFuncSetAttribute");
+  for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
+    if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, true), big)) != hipSuccess)
+      return bail(e, "hipFuncSetAttribute");
   if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
       (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
@@ -2144,6 +2315,9 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_refr) (void)hipFree(ctx->d_refr);
   if (ctx->d_cubes) (void)hipFree(ctx->d_cubes);
   if (ctx->d_occl) (void)hipFree(ctx->d_occl);
+  if (ctx->d_grid_start) (void)hipFree(ctx->d_grid_start);
+  if (ctx->d_grid_items) (void)hipFree(ctx->d_grid_items);
+  if (ctx->d_grid_big) (void)hipFree(ctx->d_grid_big);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -2165,6 +2339,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (option == RT_OPT_KERNEL && (value == RT_KERNEL_STREAM || value == RT_KERNEL_PIXEL)) {
     ctx->kernel = value;
+    return RT_OK;
+  }
+  if (option == RT_OPT_SPHERE_GRID && (value == 0 || value == 1)) {
+    ctx->sphere_grid = value != 0;      // takes effect at the next rt_upload_scene
     return RT_OK;
   }
   if (option == RT_OPT_OCCLUDER_TABLE && (value == 0 || value == 1)) {
@@ -2224,6 +2402,20 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     std::vector<uint32_t> occl;
     build_occluder_table(geom4, n_spheres, L, occl, ctx->occluder_table);
     RT_HIP(ctx, hipMemcpy(ctx->d_occl, occl.data(), sizeof(uint32_t) * occl.size(), hipMemcpyHostToDevice));
+  }
+  {
+    SphereGrid grid;
+    if (ctx->sphere_grid) build_sphere_grid(geom4, n_spheres, grid);
+    if (grid.dim > 0) {
+      RT_HIP(ctx, hipMemcpy(ctx->d_grid_start, grid.start.data(), sizeof(uint32_t) * grid.start.size(), hipMemcpyHostToDevice));
+      if (!grid.items.empty())
+        RT_HIP(ctx, hipMemcpy(ctx->d_grid_items, grid.items.data(), sizeof(uint16_t) * grid.items.size(), hipMemcpyHostToDevice));
+      if (!grid.big.empty())
+        RT_HIP(ctx, hipMemcpy(ctx->d_grid_big, grid.big.data(), sizeof(uint16_t) * grid.big.size(), hipMemcpyHostToDevice));
+      for (int k = 0; k < 3; ++k) { ctx->grid_min[k] = grid.mn[k]; ctx->grid_inv_cell[k] = grid.inv_cell[k]; ctx->grid_cell[k] = grid.cell[k]; }
+    }
+    ctx->grid_dim = grid.dim;
+    ctx->grid_n_big = int(grid.big.size());
   }
   ctx->n_spheres = n_spheres;
   ctx->has_refr = false;   // Material's defaults (raytracer.py:43) until rt_set_refraction says otherwise

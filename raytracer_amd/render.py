@@ -40,7 +40,7 @@ class Renderer:
         _lib.check(self._L.rt_create(self.device, ctypes.byref(h)))
         self._h = h
         self._packed: PackedScene | None = None
-        self._options = {"occluder_table": True}     # options that take effect at upload time
+        self._options = {"occluder_table": True, "sphere_grid": True}     # options that take effect at upload time
         self._uploaded_options = None
         self.use_torch_stream()
 
@@ -213,6 +213,12 @@ class Renderer:
         Takes effect at the next upload_scene."""
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_OCCLUDER_TABLE, 1 if on else 0))
         self._options["occluder_table"] = bool(on)
+
+    def set_sphere_grid(self, on: bool):
+        """Reflection rays of many-sphere scenes walk a uniform grid (default) or test every sphere; same
+        images.  Takes effect at the next upload_scene."""
+        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_SPHERE_GRID, 1 if on else 0))
+        self._options["sphere_grid"] = bool(on)
 
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""

@@ -245,6 +245,31 @@ def test_occluder_table_changes_no_byte(renderer):
         renderer.set_occluder_table(True)
 
 
+def test_sphere_grid_changes_no_byte(renderer):
+    """Reflection rays through the uniform grid (scenes with >= 128 spheres) find the same hits as the plain
+    scan: byte-identical frames and hit maps with RT_OPT_SPHERE_GRID on and off, depth up to 8, other cameras,
+    and a scene with two huge spheres (listed as `big`, tested up front)."""
+    import torch
+    from raytracer_amd.scenes import Material, Sphere, Vector3
+    big = generate_scene(300, 11)
+    big["spheres"].append(Sphere(Vector3(0, -1004, -10), 1000, Material(Vector3(0.8, 0.8, 0.8), specular=0.3, reflection=0.4)))
+    big["spheres"].insert(5, Sphere(Vector3(30, 0, -40), 25, Material(Vector3(0.9, 0.5, 0.5), specular=0.3, reflection=0.6)))
+    cases = [(generate_scene(128, 4), 640, 360, 5), (generate_scene(200, 5), 640, 360, 8), (generate_scene(1024, 3), 960, 540, 5),
+             (generate_scene(2000, 6), 480, 270, 3), (big, 640, 360, 6)]
+    try:
+        for scene, w, h, D in cases:
+            out = []
+            for on in (True, False):
+                renderer.set_sphere_grid(on)
+                renderer.upload_scene(scene)
+                out.append([renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=3, camera=cam, return_hit_index=True)
+                            for cam in (None, orbit_camera(37, 256), orbit_camera(150, 256, radius=14.0))])
+            for (a, ha), (b, hb) in zip(*out):
+                assert torch.equal(a, b) and torch.equal(ha, hb)
+    finally:
+        renderer.set_sphere_grid(True)
+
+
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
     pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""
