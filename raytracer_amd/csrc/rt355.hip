@@ -1951,7 +1951,9 @@ void build_sphere_grid(const float* geom4, int n, SphereGrid& g) {
       hi[k] = std::max(hi[k], double(geom4[4 * i + k]) + r);
     }
   }
-  const int G = std::max(4, std::min(kGridMaxDim, int(std::cbrt(4.0 * n) + 0.5)));
+  // 8 cells per sphere (1 ... 32 measured within 15 % of each other on config 4; the cell table in LDS
+  // instead of global memory is no faster and costs occupancy; separate walk / test loops are slower)
+  const int G = std::max(4, std::min(kGridMaxDim, int(std::cbrt(8.0 * n) + 0.5)));
   double cell[3];
   for (int k = 0; k < 3; ++k) {
     const double pad = 1e-3 * (hi[k] - lo[k]) + 1e-3;
