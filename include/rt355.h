@@ -89,7 +89,7 @@ int rt_synchronize(rt_ctx* ctx);
  *   RT_OPT_OCCLUDER_TABLE: 1 (default) = the shadow scan of a hit on object k only looks at the spheres
  *   that can shadow some point of k (see rt_occluder_table); 0 = at every sphere, as the reference
  *   does.  Images are byte-identical either way (tests); takes effect at the next rt_upload_scene.
- *   RT_OPT_SPHERE_GRID: 1 (default) = reflection rays of scenes with >= 128 spheres (no cubes, no
+ *   RT_OPT_SPHERE_GRID: 1 (default) = reflection rays of scenes with >= 256 spheres (no cubes, no
  *   refraction) walk a uniform grid built at scene upload instead of testing every sphere; 0 = the
  *   plain scan of find_nearest_intersection (raytracer.py:152-172).  Same images (tests); takes effect
  *   at the next rt_upload_scene. */

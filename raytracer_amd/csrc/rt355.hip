@@ -1931,7 +1931,7 @@ struct Window {
 // Uniform grid for nearest_grid(): G^3 cells over the bounding box of the spheres, G ~ cbrt(4 n).  A cell
 // lists every sphere whose bounding box, grown by 2 % of a cell, touches it (ascending indices); spheres
 // that would be listed in more than kGridMaxCellsPerSphere cells go to `big` instead.
-constexpr int kGridFrom = 128;                 // scenes with at least this many spheres get a grid
+constexpr int kGridFrom = 256;                 // scenes with at least this many spheres get a grid (measured crossover: ~230)
 constexpr int kGridMaxDim = 32;
 constexpr int kGridMaxCellsPerSphere = 64;
 struct SphereGrid {

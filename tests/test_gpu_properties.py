@@ -246,7 +246,7 @@ def test_occluder_table_changes_no_byte(renderer):
 
 
 def test_sphere_grid_changes_no_byte(renderer):
-    """Reflection rays through the uniform grid (scenes with >= 128 spheres) find the same hits as the plain
+    """Reflection rays through the uniform grid (scenes with >= 256 spheres) find the same hits as the plain
     scan: byte-identical frames and hit maps with RT_OPT_SPHERE_GRID on and off, depth up to 8, other cameras,
     and a scene with two huge spheres (listed as `big`, tested up front)."""
     import torch
@@ -254,7 +254,7 @@ def test_sphere_grid_changes_no_byte(renderer):
     big = generate_scene(300, 11)
     big["spheres"].append(Sphere(Vector3(0, -1004, -10), 1000, Material(Vector3(0.8, 0.8, 0.8), specular=0.3, reflection=0.4)))
     big["spheres"].insert(5, Sphere(Vector3(30, 0, -40), 25, Material(Vector3(0.9, 0.5, 0.5), specular=0.3, reflection=0.6)))
-    cases = [(generate_scene(128, 4), 640, 360, 5), (generate_scene(200, 5), 640, 360, 8), (generate_scene(1024, 3), 960, 540, 5),
+    cases = [(generate_scene(256, 4), 640, 360, 5), (generate_scene(400, 5), 640, 360, 8), (generate_scene(1024, 3), 960, 540, 5),
              (generate_scene(2000, 6), 480, 270, 3), (big, 640, 360, 6)]
     try:
         for scene, w, h, D in cases:
