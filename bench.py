@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
-MEASURED_TRAFFIC_C2 = 7.5e9         # bytes per 256-frame launch pair, profiles/r1k_c2_* (see roofline.traffic)
+MEASURED_TRAFFIC_C2 = 6.5e9         # bytes per 256-frame launch pair, profiles/r1l_c2_* (see roofline.traffic)
 PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 core (cannot run here)
 
 WORKLOADS = {
@@ -236,8 +236,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          # HBM bytes per launch pair: a separate rocprofv3 --pmc pass of this same command
                          # (tools/profile.sh; TCC_EA0_WRREQ_sum x 64 B + TCC_EA0_RDREQ_sum x 64 B x 2, the
-                         # gfx950 correction of MI355X_MICROARCH.md), profiles/r1k_c2_*: visibility 2.9e9 W,
-                         # stream 4.4e9 W + 2.2e8 R.  Known for the default workload only.
+                         # gfx950 correction of MI355X_MICROARCH.md), profiles/r1l_c2_*: visibility 1.9e9 W,
+                         # stream 4.3e9 W + 2.1e8 R.  Known for the default workload only.
                          "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 256 and args.samples == 1
                                                             and world == 1 and args.kernel == "stream") else None,
                          "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
@@ -247,8 +247,8 @@ def main():
                          "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d, i.e. "
                                  "the brute-force count of the reference's algorithm: the kernels cull spheres (per object, per "
                                  "shading point, per ray bundle) and execute ~3x fewer flops, so frac exceeds 1 on "
-                                 "many-sphere scenes (DESIGN.md 4, roofline); HBM traffic (PMC, profiles/r1k_*) is "
-                                 "~7.5e9 B per 256-frame config-2 launch: the framebuffer, 2.25 B/pixel of hit indices and the "
+                                 "many-sphere scenes (DESIGN.md 4, roofline); HBM traffic (PMC, profiles/r1l_*) is "
+                                 "~6.5e9 B per 256-frame config-2 launch: the framebuffer, 2.25 B/pixel of hit indices and the "
                                  "scattered pixel stores"},
         }
         if world == 1 and not args.no_cpu_baseline:
