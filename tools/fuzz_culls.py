@@ -13,9 +13,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = Renderer(0)
 bad = 0
 for case in range(n_cases):
-    n = int(rng.choice([3, 8, 20, 64, 150, 400]))
+    n = int(rng.choice([3, 8, 20, 64, 150, 400, 1000, 2040]))
     sc = generate_scene(n, int(rng.integers(1, 1000)), keep_default=bool(rng.integers(0, 2)) and n >= 3)
     sph = sc["spheres"]
+    if rng.integers(0, 4) == 0:      # a huge "floor" and a large far sphere: the grid's `big` list, table rows of all ones
+        from raytracer_amd.scenes import Material, Sphere
+        sph.append(Sphere(Vector3(0, -1003.5, -10), 1000, Material(Vector3(0.8, 0.8, 0.8), specular=0.3, reflection=0.4)))
+        sph.insert(0, Sphere(Vector3(25, 5, -45), 20, Material(Vector3(0.9, 0.5, 0.5), specular=0.3, reflection=0.6)))
     def rand_pos():
         mode = rng.integers(0, 4)
         if mode == 0:   # somewhere around the scene
@@ -31,6 +35,7 @@ for case in range(n_cases):
                                  Vector3(1, 1, 1), 0.9, samples=int(rng.choice([1, 4, 12, 20])))
     cam = None if rng.integers(0, 3) == 0 else orbit_camera(int(rng.integers(0, 256)), 256, radius=float(rng.uniform(3, 12)))
     w, h, D = int(rng.integers(100, 500)), int(rng.integers(60, 300)), int(rng.integers(0, 7))
+    if n >= 1000: w, h = min(w, 240), min(h, 135)
     outs = []
     for table, kernel in ((True, "stream"), (False, "stream"), (True, "pixel")):
         r.set_occluder_table(table); r.set_kernel(kernel); r.upload_scene(sc)
