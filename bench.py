@@ -124,10 +124,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: rt355 has no CPU path")
+    # RT_BENCH_BACKEND=gloo rehearses the N > 1 code path with all ranks on the GPUs that exist (slabs are
+    # staged through host memory); the driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from raytracer_amd.distributed import BatchExchange
     from raytracer_amd.render import Renderer
@@ -194,12 +202,13 @@ def main():
     dt = time.perf_counter() - t0
 
     rc = r.ray_counts()
-    stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    red_dev = "cpu" if backend == "gloo" else dev
+    stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     from raytracer_amd._lib import FRAMES_PER_LAUNCH
     launches_per_step = -(-F // FRAMES_PER_LAUNCH) * args.samples
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
-    kmax = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -89,6 +89,18 @@ class BatchExchange:
         if self.world == 1:
             self.place(self.slabs[b].unsqueeze(0), step)
             return
+        if self.slabs[b].is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal of the N > 1 path on one GPU (bench.py RT_BENCH_BACKEND=gloo): gloo has no gather for
+            # device tensors, so the slabs go through host memory, synchronously
+            import torch
+            host = self.slabs[b].cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            self.dist.gather(host, parts, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                self.gathered[b].copy_(torch.stack(parts))
+            self.pending[b] = (None, step)
+            self._finish(1 - b)
+            return
         parts = list(self.gathered[b].unbind(0)) if self.rank == self.dst else None
         work = self.dist.gather(self.slabs[b], parts, dst=self.dst, group=self.group, async_op=True)
         self.pending[b] = (work, step)
@@ -99,7 +111,8 @@ class BatchExchange:
             return
         work, step = self.pending[b]
         self.pending[b] = None
-        work.wait()                      # nccl: the current stream waits; gloo: the host does
+        if work is not None:
+            work.wait()                  # nccl: the current stream waits; gloo: the host does
         if self.rank == self.dst:
             self.place(self.gathered[b], step)
 

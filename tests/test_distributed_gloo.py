@@ -110,3 +110,59 @@ def test_batch_exchange_single_process():
         ex.submit(i)
     ex.drain()
     assert seen == [(0, (1, 2, 8), 1), (1, (1, 2, 8), 2), (2, (1, 2, 8), 3)]
+
+
+def _gpu_exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import tiling
+        from raytracer_amd.distributed import BatchExchange
+        from raytracer_amd.render import Renderer
+        from raytracer_amd.scenes import generate_scene, orbit_camera
+        w, h, tr, F, steps = 320, 187, 8, 5, 3
+        r = Renderer(0)
+        r.upload_scene(generate_scene(8, 1, keep_default=True))
+        rows_max = tiling.max_local_rows(h, tr, world)
+        frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0")
+        ok = []
+
+        def place(gathered, i):          # rank 0: assemble batch i and compare it with whole-frame renders
+            r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out)
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
+            ok.append(bool(torch.equal(frames_out, full)))
+
+        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place)
+        for i in range(steps):
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=ex.slab(i).view(F, rows_max, w, 3),
+                            tile_rows=tr, tile_first=rank, tile_stride=world)
+            ex.submit(i)
+        ex.drain()
+        if rank == 0:
+            q.put(ok)
+        r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_batch_exchange_of_gpu_row_tiles(world):
+    """bench.py's N > 1 step on the GPU: `world` processes (all on cuda:0 here) each render their row tiles
+    of a batch with the HIP library, the slabs are gathered (gloo, staged through host memory — RCCL
+    needs one GPU per rank) and rank 0 places them with rt_scatter_rows_frames: the assembled frames
+    are byte-identical to whole-frame renders."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(170)
+        assert p.exitcode == 0
+    ok = q.get(timeout=5)
+    assert ok == [True, True, True]
