@@ -1218,23 +1218,22 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 // STREAM KERNEL (second half of the default path): persistent WAVES, each with its own work lists.
 //
 // The launch holds 4 workgroups of 4 waves per CU (4 waves per SIMD).  A workgroup only shares the
-// LDS copies of the sphere list and the batch's cameras; after the one barrier that publishes them,
-// every wave runs on its own.  Work arrives as 8x8 tiles of the frames of the batch, claimed from
-// global counters until none is left.  Per wave, in LDS:
-//   pending list : hit pixels of the tiles taken in so far — one coalesced 128-byte load of the
-//                  visibility pass's tile-major indices per tile, ballot + prefix count, 8-byte
-//                  entries {column, row, frame, sphere}.
-//   bounce queue : records {P, D, T, acc, pixel, level|frame|sphere, pixel key} of reflection rays
-//                  that hit something.
-// A shading pass takes 64 items — bounce records first, the rest from the pending list, whose
-// primary ray and hit point are rebuilt exactly as the visibility pass measured them — and per lane
-// runs compute_lighting with its 13 x N shadow tests, the throughput update, the reflection ray
-// and its nearest-hit scan; a new hit goes onto the bounce queue, anything else finishes the pixel
-// (3 byte stores into the frame the visibility pass has already cleared).  Both lists live across
-// tiles and frames, so a wave runs partially filled only in its final drain — not wherever pixels
-// miss or die at different depths (the pixel kernel below, kept for A/B evidence).  No barrier and
-// no LDS atomic sits on this path: waves drift apart, so one wave's memory-latency-bound intake
-// overlaps another's VALU-bound shading on the same SIMD.
+// LDS copy of the sphere list; after the one barrier that publishes it, every wave runs on its
+// own.  Work arrives as 8x8 tiles of the frames of the batch, claimed from global counters until
+// none is left.  Per wave, in LDS, one work queue of records {P, D, T, acc, pixel,
+// level|frame|object, pixel key} of rays that hit something:
+//   intake : one coalesced load of a tile's record (the visibility pass's hit indices + header);
+//            the tile's frame is wave-uniform, so its camera and seed come by scalar load, and
+//            every hit pixel rebuilds its primary ray and hit point exactly as the visibility
+//            pass measured them and becomes a level-0 record (ballot + prefix count).
+//   pass   : the 64 records on top of the queue; per lane compute_lighting with its shadow tests,
+//            the throughput update, the reflection ray and its nearest-hit scan; a new hit goes
+//            back onto the queue, anything else finishes the pixel (3 byte stores into the frame
+//            the visibility pass has already cleared).
+// The queue lives across tiles and frames, so a wave runs partially filled only in its final
+// drain — not wherever pixels miss or die at different depths (the pixel kernel below, kept for
+// A/B evidence).  No barrier and no LDS atomic sits on this path: waves drift apart, so one
+// wave's memory-latency-bound intake overlaps another's VALU-bound shading on the same SIMD.
 //
 // Work distribution.  A launch is short (a 16-frame 1080p batch: ~50 passes per wave) and the cost
 // of a tile ranges from nothing (sky) to 6 passes (64 pixels of facing mirrors), so the unit handed
@@ -1259,8 +1258,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 //     that still has tiles becomes its counter, and claiming goes on there through the same
 //     pipelined, guided-size path (one-tile synchronous claims at the end cost 8-9 % at 64 spheres).
 // ------------------------------------------------------------------------------------------
-constexpr int kPendingCap = 128;                      // <= 63 left over + one tile
-constexpr int kBounceCap = 64;                        // a pass takes ALL queued records (<= 64), then pushes <= 64
+constexpr int kBounceCap = 128;                       // <= 63 records when a tile is taken in (<= 64 more); a pass takes 64 and pushes <= 64
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
 #ifndef RT_RING
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
@@ -1284,7 +1282,7 @@ struct Queue {
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
 constexpr int wave_lds_bytes(bool refr) {
-  return kQueueFields * (refr ? kBounceCapRefr : kBounceCap) * 4 + kPendingCap * 8 + kRing * kVisTile * 2;
+  return kQueueFields * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2;
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -1306,23 +1304,13 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
   const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
-  float* s_cams = reinterpret_cast<float*>(smem + geom_bytes);                 // [frames of the batch][12]
-  const int frames_lds = (p.n_frames + 3) & ~3;                               // (keeps what follows 16-byte aligned)
-  uint32_t* s_seeds = reinterpret_cast<uint32_t*>(s_cams + frames_lds * 12);   // [frames_lds]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  unsigned char* mine = reinterpret_cast<unsigned char*>(s_seeds + frames_lds) + wave * kWaveLdsBytes;
+  unsigned char* mine = smem + geom_bytes + wave * kWaveLdsBytes;
   Queue<kCap> q{reinterpret_cast<float*>(mine)};
-  uint2* pend = reinterpret_cast<uint2*>(mine + kQueueFields * kCap * 4);
-  int16_t* ring = reinterpret_cast<int16_t*>(pend + kPendingCap);               // [kRing][kVisTile] tile records
+  int16_t* ring = reinterpret_cast<int16_t*>(mine + kQueueFields * kCap * 4);   // [kRing][kVisTile] tile records
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   if constexpr (CUBES)
     for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
-  for (int i = tid; i < p.n_frames * 16; i += kBlock) {   // FrameRec = 12 camera floats, seed, 3 pad words
-    const uint32_t v = reinterpret_cast<const uint32_t*>(p.frames)[i];
-    const int f = i >> 4, k = i & 15;
-    if (k < 12) s_cams[f * 12 + k] = __uint_as_float(v);
-    else if (k == 12) s_seeds[f] = v;
-  }
   __syncthreads();   // the only workgroup-wide synchronisation
 
   const int tiles_per_frame = p.tile_pitch * p.tiles8_y;   // tile ids, padding ids (no record, no occupancy bit) included
@@ -1332,7 +1320,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   uint32_t n_trace = 0, n_shade = 0;
   unsigned long long st_fetch = 0, st_pop = 0, st_light = 0, st_near = 0;
   const unsigned long long st_begin = RT_NOW();
-  int n_bounce = 0, n_pend = 0;   // wave-uniform list lengths
+  int n_bounce = 0;               // wave-uniform queue length
   bool done = false;              // no tile is left for this wave
 
   // ---- tile supply (all wave-uniform).  Slot s of counter h is tile s * K + h; counter h has
@@ -1369,7 +1357,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
 
   for (;;) {
     // ------------------------------ tile intake ------------------------------------------
-    if (n_bounce + n_pend < 64 && !done) {
+    if (n_bounce < 64 && !done) {
       const unsigned long long s0 = RT_NOW();
       // Take tiles from the ring until a full pass is available, then refill the ring.  Those loads
       // (and the next claim's atomic) fly during the coming pass, so the waits below are normally
@@ -1458,24 +1446,56 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         if (mask != 0ull) {                                  // else: empty tile (sky)
           const uint2 m = *reinterpret_cast<const uint2*>(ring + slot * kVisTile + 64);   // the record's header
           const uint32_t m0 = __builtin_amdgcn_readfirstlane(m.x), m1 = __builtin_amdgcn_readfirstlane(m.y);
-          const uint32_t col = (m0 & 0xFFFFu) * 8u + uint32_t(lane & 7), row = (m0 >> 16) * 8u + uint32_t(lane >> 3);
-          if (idx >= 0)                  // entry: column | frame << 24,  row | sphere << 20
-            pend[n_pend + lanes_below(mask)] = make_uint2(col | (m1 << 24), row | (uint32_t(idx) << 20));
-          n_pend += __popcll(mask);
+          const int col = int((m0 & 0xFFFFu) * 8u) + (lane & 7), row = int((m0 >> 16) * 8u) + (lane >> 3);
+          // The tile's frame is wave-uniform: its camera and seed come by scalar load.  Every hit pixel of
+          // the tile becomes a level-0 record on the queue now, with all its lanes at work: the primary
+          // ray and its hit point are rebuilt exactly as the visibility pass measured them.
+          const int frame = int(m1);
+          const FrameRec fr = as_const(p.frames)[frame];
+          if (idx >= 0) {
+            const rt_camera& cam = fr.cam;
+            const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
+            uint32_t pixel_key;
+            float dx, dy, dz, px, py, pz;
+            primary_ray<MODE>(p, cam, fr.seed, p.x0 + col, y, p.sample_index, pixel_key, dx, dy, dz);
+            if (CUBES && idx >= p.n_spheres) {
+              float t = 0.f;
+              int face = 0;
+              const int c = idx - p.n_spheres;
+              cube_t(sg[p.n_spheres + 2 * c], sg[p.n_spheres + 2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2],
+                     dx, dy, dz, frcp(dx), frcp(dy), frcp(dz), t, face);
+              hit_point<CUBES>(sg, p.n_spheres, idx, face, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t,
+                               px, py, pz);                                                                        // :168
+            } else {
+              const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+              float dl;
+              const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
+              px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
+            }
+            const int e = n_bounce + lanes_below(mask);
+            q.at(0, e) = px; q.at(1, e) = py; q.at(2, e) = pz;
+            q.at(3, e) = dx; q.at(4, e) = dy; q.at(5, e) = dz;
+            q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
+            q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f;        // acc = 0
+            q.at(12, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
+            // meta: level (8 bits) | frame (8 bits) | object index (16 bits)
+            q.at(13, e) = __uint_as_float(0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16));
+            q.at(14, e) = __uint_as_float(pixel_key);
+          }
+          n_bounce += __popcll(mask);
         }
-        if (n_bounce + n_pend >= 64) consuming = false;      // one more turn: refill, then shade
+        if (n_bounce >= 64) consuming = false;               // one more turn: refill, then shade
       }
       wave_lds_fence();
       st_fetch += RT_NOW() - s0;
       continue;
     }
-    if (n_bounce + n_pend == 0) break;
+    if (n_bounce == 0) break;
 
     // ------------------------------ shading pass -----------------------------------------
     {
       const unsigned long long s0 = RT_NOW();
-      int nb = min(64, n_bounce);                                   // bounce records: lanes [0, nb)
-      int np = min(64 - nb, n_pend);                                // pending hits:   lanes [nb, nb + np)
+      int nb = min(64, n_bounce);                                   // the top records of the queue: lanes [0, nb)
       if constexpr (REFR) {
         // A lane may push TWO records, so the queue can grow; it holds kCap records.  Records are taken
         // from its top (deepest first) and a pass is sized from the levels found there: a record at
@@ -1483,11 +1503,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         // run of top records that either leaves no more than H = kCap - max_depth records behind, or
         // contains at most one pushing record.  The second case is a depth-first walk below that
         // record (one more record per level at most), which keeps every record's position below
-        // H + its level: the queue never holds more than H + max_depth = kCap records.  Pending hits
-        // (level 0) fill the lanes that are left while the first bound allows.
-        static_assert(kCap >= RT_MAX_DEPTH + 2 * 64, "a full pass of fresh hits must fit below the high-water mark");
+        // H + its level: the queue never holds more than H + max_depth = kCap records.  (Fresh level-0
+        // records are put at positions below 128 <= H by the intake, which runs only below 64 records.)
+        static_assert(kCap >= RT_MAX_DEPTH + 2 * 64, "a tile's fresh hits must fit below the high-water mark");
         const int high = kCap - p.max_depth;
-        int pushes = 0;
         if (nb > 0) {
           const bool mine = lane < nb;                               // lane l looks at the l-th record from the top
           const uint32_t mt = mine ? __float_as_uint(q.at(13, n_bounce - 1 - lane)) : 0u;
@@ -1497,13 +1516,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           const bool fits = mine && (n_bounce - (lane + 1) + 2 * upto <= high || upto <= 1);
           const unsigned long long fm = __ballot(fits);              // bit 0 is always set
           nb = 64 - __clzll((long long)fm);
-          pushes = __popcll(nb >= 64 ? pm : (pm & ((1ull << nb) - 1ull)));
         }
-        const int after = n_bounce - nb + 2 * pushes;
-        np = min(min(64 - nb, n_pend), p.max_depth > 0 ? max(0, (high - after) / 2) : 64);
       }
-      const int base = n_bounce - nb, base_p = n_pend - np;
-      const bool have = lane < nb + np;
+      const int base = n_bounce - nb;
+      const bool have = lane < nb;
       // Lane l works on record slot e = base + l.  Only what the lighting loops need comes into
       // registers now (P, D, meta, key); T, acc and the pixel stay in the slot until after them.
       const int e = base + lane;
@@ -1514,39 +1530,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         dx = q.at(3, e); dy = q.at(4, e); dz = q.at(5, e);
         meta = __float_as_uint(q.at(13, e));
         pixel_key = __float_as_uint(q.at(14, e));
-      } else if (have) {
-        const uint2 pe = pend[base_p + lane - nb];
-        const int col = int(pe.x & 0xFFFFFu), frame = int(pe.x >> 24);
-        const int row = int(pe.y & 0xFFFFFu), idx = int(pe.y >> 20);
-        const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
-        rt_camera cam;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) (&cam.origin[0])[k] = s_cams[frame * 12 + k];
-        // rebuild the primary ray and its hit point exactly as the visibility pass measured them
-        primary_ray<MODE>(p, cam, s_seeds[frame], p.x0 + col, y, p.sample_index, pixel_key, dx, dy, dz);
-        if (CUBES && idx >= p.n_spheres) {
-          float t = 0.f;
-          int face = 0;
-          const int c = idx - p.n_spheres;
-          cube_t(sg[p.n_spheres + 2 * c], sg[p.n_spheres + 2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2],
-                 dx, dy, dz, frcp(dx), frcp(dy), frcp(dz), t, face);
-          hit_point<CUBES>(sg, p.n_spheres, idx, face, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t,
-                           px, py, pz);                                                                        // :168
-        } else {
-          const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-          float dl;
-          const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
-          px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
-        }
-        // meta: level (8 bits) | frame (8 bits) | sphere index (16 bits)
-        meta = 0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16);
-        // a fresh level-0 record: T = 1, acc = 0 (slots [base + nb, base + 64) are free)
-        q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;
-        q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f;
-        q.at(12, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
-        q.at(14, e) = __uint_as_float(pixel_key);
       }
-      n_pend = base_p;
       wave_lds_fence();
       const unsigned long long s1 = RT_NOW();
       unsigned long long s2 = s1;
@@ -1909,8 +1893,8 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres, bool refr = false, int n_frames = kMaxBatch) {   // cameras and seeds of the batch's frames
-  return geom_lds(n_spheres) + size_t((n_frames + 3) & ~3) * 13 * 4 + size_t(wave_lds_bytes(refr)) * (kBlock / 64);
+size_t stream_lds(int n_spheres, bool refr = false) {
+  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr)) * (kBlock / 64);
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -2172,7 +2156,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
-    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, nf) : pixel_lds(ctx->n_spheres);
+    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = ctx->d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
