@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|t64|c3|c1]
 
-One "step" = one batch of ``--frames`` (default 64, = one kernel launch pair) 1080p frames of BASELINE.json config 2
+One "step" = one batch of ``--frames`` (default 1024, = one kernel launch pair) 1080p frames of BASELINE.json config 2
 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per shaded hit, keyed RNG, seed = frame
 index), inputs (scene) already resident on the GPU.  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
-MEASURED_TRAFFIC_C2 = 6.5e9         # bytes per 256-frame launch pair, profiles/r1l_c2_* (see roofline.traffic)
+MEASURED_TRAFFIC_C2 = 3.26e10       # bytes per 1024-frame launch pair, profiles/r1m_c2_* (see roofline.traffic)
 PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 core (cannot run here)
 
 WORKLOADS = {
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=256, help="frames per step (batch)")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per step (batch)")
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--kernel", default="stream", choices=["stream", "pixel"])
@@ -149,6 +149,8 @@ def main():
     r = Renderer(local_rank)
     r.upload_scene(packed)
     r.set_kernel(args.kernel)
+    if os.environ.get("RT_BENCH_NO_SPILL"):     # A/B of the refractive queue's spill stack
+        r.set_queue_spill(False)
 
     rows_max = tiling.max_local_rows(h, tr, world)
     slab_bytes = rows_max * w * 3
@@ -206,7 +208,8 @@ def main():
     stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     from raytracer_amd._lib import FRAMES_PER_LAUNCH
-    launches_per_step = -(-F // FRAMES_PER_LAUNCH) * args.samples
+    # (refractive scenes go 256 frames per launch pair: kRefrBatch in csrc/rt355.hip)
+    launches_per_step = -(-F // (min(256, FRAMES_PER_LAUNCH) if packed.has_refraction else FRAMES_PER_LAUNCH)) * args.samples
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
     kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -245,19 +248,19 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          # HBM bytes per launch pair: a separate rocprofv3 --pmc pass of this same command
                          # (tools/profile.sh; TCC_EA0_WRREQ_sum x 64 B + TCC_EA0_RDREQ_sum x 64 B x 2, the
-                         # gfx950 correction of MI355X_MICROARCH.md), profiles/r1l_c2_*: visibility 1.9e9 W,
-                         # stream 4.3e9 W + 2.1e8 R.  Known for the default workload only.
-                         "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 256 and args.samples == 1
+                         # gfx950 correction of MI355X_MICROARCH.md), profiles/r1m_c2_*: visibility 7.7e9 W,
+                         # stream 2.37e10 W + 1.1e9 R.  Known for the default workload only.
+                         "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 1024 and args.samples == 1
                                                             and world == 1 and args.kernel == "stream") else None,
                          "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
-                                    "also cover the ~4 us rt_camera_table_kernel, four frame-record stores and a 1 MB memset)")
+                                    "also cover the ~4 us rt_camera_table_kernel, up to 16 frame-record stores and a 4 MB memset)")
                          if args.kernel == "stream" else "rt_pixel_kernel", "kernel_ms": kern_ms,
                          "flops_per_launch": fl,
                          "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d, i.e. "
                                  "the brute-force count of the reference's algorithm: the kernels cull spheres (per object, per "
                                  "shading point, per ray bundle) and execute ~3x fewer flops, so frac exceeds 1 on "
-                                 "many-sphere scenes (DESIGN.md 4, roofline); HBM traffic (PMC, profiles/r1l_*) is "
-                                 "~6.5e9 B per 256-frame config-2 launch: the framebuffer, 2.25 B/pixel of hit indices and the "
+                                 "many-sphere scenes (DESIGN.md 4, roofline); HBM traffic (PMC, profiles/r1m_*) is "
+                                 "~3.3e10 B per 1024-frame config-2 launch: the framebuffer, 2.25 B/pixel of hit indices and the "
                                  "scattered pixel stores"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@ extern "C" {
 #define RT_MAX_SPHERES 2048      /* 16 B of LDS per sphere in the shading kernels: 32 KiB      */
 #define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
 #define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
-#define RT_FRAMES_PER_LAUNCH 256 /* frames of a batch that share one kernel launch pair        */
+#define RT_FRAMES_PER_LAUNCH 1024 /* frames of a batch that share one kernel launch pair       */
 
 #define RT_OK 0
 #define RT_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned)          */
@@ -92,10 +92,15 @@ int rt_synchronize(rt_ctx* ctx);
  *   RT_OPT_SPHERE_GRID: 1 (default) = reflection rays of scenes with >= 256 spheres (no cubes, no
  *   refraction) walk a uniform grid built at scene upload instead of testing every sphere; 0 = the
  *   plain scan of find_nearest_intersection (raytracer.py:152-172).  Same images (tests); takes effect
- *   at the next rt_upload_scene. */
+ *   at the next rt_upload_scene.
+ *   RT_OPT_QUEUE_SPILL: 1 (default) = on refractive scenes a wave of the stream kernel whose work queue
+ *   cannot take a full pass's children sets its 64 shallowest records aside in device memory (<= 32 blocks of
+ *   3 KB per wave, allocated on first use) instead of shrinking the pass; 0 = shrink only.  Same images to
+ *   float summation order (tests). */
 #define RT_OPT_KERNEL 1
 #define RT_OPT_OCCLUDER_TABLE 2
 #define RT_OPT_SPHERE_GRID 3
+#define RT_OPT_QUEUE_SPILL 4
 #define RT_KERNEL_STREAM 0
 #define RT_KERNEL_PIXEL 1
 int rt_set_option(rt_ctx* ctx, int option, int value);

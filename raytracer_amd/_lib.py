@@ -12,10 +12,11 @@ _SO = os.environ.get("RT355_LIB") or os.path.join(os.path.dirname(os.path.abspat
 _lib = None
 
 RT_RNG_CONSTANT, RT_RNG_KEYED = 0, 1
-FRAMES_PER_LAUNCH = 256    # RT_FRAMES_PER_LAUNCH of include/rt355.h
+FRAMES_PER_LAUNCH = 1024   # RT_FRAMES_PER_LAUNCH of include/rt355.h
 RT_OPT_KERNEL, RT_KERNEL_STREAM, RT_KERNEL_PIXEL = 1, 0, 1
 RT_OPT_OCCLUDER_TABLE = 2
 RT_OPT_SPHERE_GRID = 3
+RT_OPT_QUEUE_SPILL = 4
 RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT: RT_RNG_CONSTANT,
              "K": RT_RNG_KEYED, "keyed": RT_RNG_KEYED}
 

@@ -66,8 +66,17 @@ struct DevLights {
 // frames per launch: the fixed cost of a launch pair (ramp-up, the stream kernel's uneven tail, the
 // gaps between dependent launches: ~0.1 ms) is paid once per batch — 16 -> 64 frames is +14 % on config 2
 constexpr int kMaxBatch = RT_FRAMES_PER_LAUNCH;
+constexpr int kRefrBatch = 256;   // frames per launch pair of a refractive scene (see render_frames)
 struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
-static_assert(kMaxBatch <= 256, "frame numbers travel in 8 bits of the work-list records");
+static_assert(kMaxBatch <= 8192, "frame numbers travel in 13 bits of the work-queue records");
+static_assert(RT_MAX_SPHERES <= 4096 && RT_MAX_DEPTH < 127, "object index: 12 bits, level: 7 bits of a record's meta word");
+// meta word of a work-queue record: level (7 bits) | frame (13 bits) | object index (12 bits)
+__device__ __forceinline__ uint32_t pack_meta(int level, int frame, int object) {
+  return uint32_t(level) | (uint32_t(frame) << 7) | (uint32_t(object) << 20);
+}
+__device__ __forceinline__ int meta_level(uint32_t m) { return int(m & 127u); }
+__device__ __forceinline__ int meta_frame(uint32_t m) { return int((m >> 7) & 8191u); }
+__device__ __forceinline__ int meta_object(uint32_t m) { return int(m >> 20); }
 
 // Per-frame inputs of a batch.  A launch's kernel arguments are limited to 4 KB, so the cameras of up to
 // 256 frames live in device memory: rt_store_frames_kernel writes them there from kernel arguments,
@@ -130,6 +139,8 @@ struct RenderParams {
   long long frame_stride_px;     // pixels between frames in out_*
   long long accum_stride_px;     // pixels between frames in accum
   const FrameRec* frames;  // [n_frames] camera and folded seed of each frame of the batch (device; rt_store_frames_kernel)
+  float* spill;            // REFR: [wave][spill_blocks][kSpillFields][64] queue records set aside (stream kernel)
+  int spill_blocks;        // blocks of 64 records per wave in `spill`
 };
 
 #ifndef RT_VIS_TILES
@@ -1276,6 +1287,10 @@ constexpr int kClaimMax = RT_CLAIM;
 #endif
 
 constexpr int kBounceCapRefr = 192;                   // refraction: RT_MAX_DEPTH + 2 x 64, see the pass sizing in the kernel
+// Refraction: the fields a record carries (no acc: nodes add into the pixel sums), in the order they are set aside
+constexpr int kSpillFields = 12;
+__host__ __device__ constexpr int spill_field(int k) { return k < 9 ? k : k + 3; }   // 0..8, 12, 13, 14
+constexpr int kSpillBlocksMax = 32;                   // blocks of 64 records a wave may have set aside (3 KB each)
 template <int CAP>
 struct Queue {
   float* f;        // kQueueFields arrays of CAP words (field-major: conflict-free lane access)
@@ -1295,6 +1310,55 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // set bits of mask below this lane
   return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
+
+#ifndef RT_SPILL_VARIANT
+#define RT_SPILL_VARIANT 0
+#endif
+// Refraction: the bottom 64 records of a wave's queue go to its spill block `dst`, the rest moves down
+// (lane l touches positions l, 64 + l and 128 + l only: no ordering between lanes is needed)
+template <int CAP>
+#if RT_SPILL_VARIANT == 1
+__device__ __noinline__
+#else
+__device__ __forceinline__
+#endif
+void queue_set_aside(float* qf, float* dst, int lane, int n) {
+  Queue<CAP> q{qf};
+  const bool row2 = 128 + lane < n;
+#if RT_SPILL_VARIANT == 3
+#pragma nounroll
+#else
+#pragma unroll
+#endif
+  for (int k = 0; k < kSpillFields; ++k) {
+    const int f = spill_field(k);
+    dst[k * 64] = q.at(f, lane);
+    const float a = q.at(f, 64 + lane);                    // (64 + lane < 128 <= n)
+    const float b = row2 ? q.at(f, 128 + lane) : 0.f;
+    q.at(f, lane) = a;
+    if (row2) q.at(f, 64 + lane) = b;
+  }
+}
+template <int CAP>
+#if RT_SPILL_VARIANT == 1
+__device__ __noinline__
+#else
+__device__ __forceinline__
+#endif
+void queue_take_back(float* qf, const float* src, int at) {
+  Queue<CAP> q{qf};
+#if RT_SPILL_VARIANT == 3
+#pragma nounroll
+#else
+#pragma unroll
+#endif
+  for (int k = 0; k < kSpillFields; ++k) q.at(spill_field(k), at) = src[k * 64];
+}
+#if RT_SPILL_VARIANT == 2
+#define RT_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define RT_UNLIKELY(x) (x)
+#endif
 
 template <int MODE, bool REFR, bool CUBES, bool GRID = false>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams p) {
@@ -1355,7 +1419,24 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   bool supply_done = false;
   unsigned long long st_topup = 0, st_wait = 0;
 
+  // ---- REFR: records set aside in global memory (see the pass sizing below), a stack of 64-record blocks
+  int sp_blocks = 0;
+  auto sp_block = [&](int b) {   // (derived from the kernel arguments where it is needed: the main loop is short of scalar registers)
+    return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane;
+  };
+
   for (;;) {
+    if constexpr (REFR) {
+      // fewer than a pass's worth of records in LDS and a block set aside: it comes back, on top of the queue
+      // (positions below 128 <= H, like a tile's fresh hits), before any new tile is taken in
+      if (RT_UNLIKELY(n_bounce < 64 && sp_blocks > 0)) {
+        --sp_blocks;
+        queue_take_back<kCap>(q.f, sp_block(sp_blocks), n_bounce + lane);
+        n_bounce += 64;
+        wave_lds_fence();
+        continue;
+      }
+    }
     // ------------------------------ tile intake ------------------------------------------
     if (n_bounce < 64 && !done) {
       const unsigned long long s0 = RT_NOW();
@@ -1478,8 +1559,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
             q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f;        // acc = 0
             q.at(12, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
-            // meta: level (8 bits) | frame (8 bits) | object index (16 bits)
-            q.at(13, e) = __uint_as_float(0u | (uint32_t(frame) << 8) | (uint32_t(idx) << 16));
+            q.at(13, e) = __uint_as_float(pack_meta(0, frame, idx));
             q.at(14, e) = __uint_as_float(pixel_key);
           }
           n_bounce += __popcll(mask);
@@ -1505,17 +1585,36 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         // record (one more record per level at most), which keeps every record's position below
         // H + its level: the queue never holds more than H + max_depth = kCap records.  (Fresh level-0
         // records are put at positions below 128 <= H by the intake, which runs only below 64 records.)
+        //   That rule alone degenerates on scenes whose trees really branch (glass cubes: every hit has two
+        // children): the queue fills with pushing records and the passes shrink to one or two lanes.  So
+        // when the run is cut short for want of room, the BOTTOM 64 records (the shallowest) are set aside first,
+        // in a per-wave stack of blocks in global memory (12 coalesced 256-byte stores), and the rest
+        // moves down; a block comes back when fewer than 64 records are left (top of the loop).  Lane l
+        // touches positions l, 64 + l and 128 + l only, so the move needs no ordering between lanes.
+        // Positions only decrease, so the bound above still holds; when the stack is full (spill_blocks)
+        // the rule above alone keeps the queue within kCap.
         static_assert(kCap >= RT_MAX_DEPTH + 2 * 64, "a tile's fresh hits must fit below the high-water mark");
+        static_assert(kCap <= 3 * 64, "the move below handles three rows of 64 records");
         const int high = kCap - p.max_depth;
         if (nb > 0) {
           const bool mine = lane < nb;                               // lane l looks at the l-th record from the top
           const uint32_t mt = mine ? __float_as_uint(q.at(13, n_bounce - 1 - lane)) : 0u;
-          const bool pushing = mine && int(mt & 255u) < p.max_depth;
+          const bool pushing = mine && meta_level(mt) < p.max_depth;
           const unsigned long long pm = __ballot(pushing);
           const int upto = lanes_below(pm) + (pushing ? 1 : 0);      // pushing records among the top l + 1
-          const bool fits = mine && (n_bounce - (lane + 1) + 2 * upto <= high || upto <= 1);
-          const unsigned long long fm = __ballot(fits);              // bit 0 is always set
-          nb = 64 - __clzll((long long)fm);
+          auto run = [&](int n) {                                    // length of the top run of a queue of n records
+            const bool fits = mine && (n - (lane + 1) + 2 * upto <= high || upto <= 1);
+            return 64 - __clzll((long long)__ballot(fits));          // (bit 0 is always set)
+          };
+          const int want = nb;
+          nb = run(n_bounce);
+          if (RT_UNLIKELY(nb + 8 <= want && n_bounce >= 128 && sp_blocks < p.spill_blocks)) {   // cut short for want of room
+            queue_set_aside<kCap>(q.f, sp_block(sp_blocks), lane, n_bounce);
+            ++sp_blocks;
+            n_bounce -= 64;                                          // (still >= 64: the top `want` = 64 records are the same ones)
+            wave_lds_fence();
+            nb = run(n_bounce);
+          }
         }
       }
       const int base = n_bounce - nb;
@@ -1554,7 +1653,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         float fpx = 0.f, fpy = 0.f, fpz = 0.f, fdx = 0.f, fdy = 0.f, fdz = 0.f, ftr = 0.f, ftg = 0.f, ftb = 0.f;
         uint32_t meta_r = 0u, meta_f = 0u;
         if (have) {
-          const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
+          const int level = meta_level(meta), rframe = meta_frame(meta), idx = meta_object(meta);
           ++n_shade;
           const float4 m = p.mat[idx];
           const float spec = p.spec[idx];
@@ -1586,7 +1685,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
               hit_point<CUBES>(sg, p.n_spheres, idx2, face, sx, sy, sz, rdx, rdy, rdz, t, rpx, rpy, rpz);
               const float k = refl * (1.0f - refr);
               rtr = tr * k * lr; rtg = tg * k * lg; rtb = tb * k * lb;
-              meta_r = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
+              meta_r = pack_meta(level + 1, rframe, idx2);
             }
           }
           if (refr > 0.0f && deeper) {                                       // :252-253 -> compute_refraction
@@ -1613,7 +1712,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
                 push_f = true;
                 hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, fdx, fdy, fdz, t, fpx, fpy, fpz);
                 ftr = tr * refr * lr; ftg = tg * refr * lg; ftb = tb * refr * lb;
-                meta_f = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
+                meta_f = pack_meta(level + 1, rframe, idx2);
               }
             }
           }
@@ -1647,7 +1746,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         continue;
       }
       if (have) {
-        const int level = int(meta & 255u), rframe = int((meta >> 8) & 255u), idx = int(meta >> 16);
+        const int level = meta_level(meta), rframe = meta_frame(meta), idx = meta_object(meta);
         ++n_shade;
         float ox, oy, oz;
         const uint32_t level_key = mix(pixel_key, uint32_t(level + 1));
@@ -1664,7 +1763,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           if (idx2 >= 0) {
             again = true;
             hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, dx, dy, dz, t, px, py, pz);
-            meta = uint32_t(level + 1) | (uint32_t(rframe) << 8) | (uint32_t(idx2) << 16);
+            meta = pack_meta(level + 1, rframe, idx2);
           }
         }
         if (!again)
@@ -1852,6 +1951,7 @@ struct rt_ctx {
   int grid_dim = 0, grid_n_big = 0;
   float grid_min[3] = {0, 0, 0}, grid_inv_cell[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0};
   bool sphere_grid = true;            // RT_OPT_SPHERE_GRID
+  bool queue_spill = true;            // RT_OPT_QUEUE_SPILL
   uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
@@ -1863,6 +1963,8 @@ struct rt_ctx {
   size_t chunk_bytes = 0;        // by the occupancy words of the batch's tiles (grown on demand)
   size_t vis_elems = 0;
   int n_cus = 256;
+  float* d_spill = nullptr;      // stream kernel, refractive scenes: queue records set aside (grown on demand)
+  size_t spill_bytes = 0;
   float* d_accum = nullptr;      // running sums for samples > 1 (grown on demand)
   size_t accum_floats = 0;
   int n_spheres = -1;
@@ -2071,9 +2173,13 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // frames per launch pair: at most RT_FRAMES_PER_LAUNCH, and few enough that tile ids stay below 2^30
   // (the kernels count tiles of a batch in 32-bit integers)
   const long long frame_tiles = (long long)(((w.nx + 7) / 8) | 1) * ((w.n_rows + 7) / 8);   // tile ids per frame (odd pitch)
-  const int max_batch = int(std::max<long long>(1, std::min<long long>(kMaxBatch, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
-  const int batch = std::min(n_frames, max_batch);
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
+  // refractive scenes add every tree node into a float slab per frame (12 B per pixel): beyond kRefrBatch
+  // frames the slabs' scattered atomics lose more to the caches than the longer launch gains (measured:
+  // glass cubes 39 -> 28 Grays/s at 1024 frames per launch)
+  const int frames_cap = refr ? std::min(kMaxBatch, kRefrBatch) : kMaxBatch;
+  const int max_batch = int(std::max<long long>(1, std::min<long long>(frames_cap, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
+  const int batch = std::min(n_frames, max_batch);
   const bool cubes = ctx->n_cubes > 0;
   if ((refr || cubes) && ctx->kernel != RT_KERNEL_STREAM)
     return fail(ctx, RT_ESTATE, "refractive materials and cubes need the default kernel (RT_KERNEL_STREAM)");
@@ -2085,6 +2191,21 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       ctx->d_accum = nullptr; ctx->accum_floats = 0;
       RT_HIP(ctx, hipMalloc(&ctx->d_accum, need * sizeof(float)));
       ctx->accum_floats = need;
+    }
+  }
+
+  // refractive scenes: per wave of the stream kernel a stack of 64-record blocks for queue records set aside
+  // (a level keeps at most ~128 records waiting while the levels below it are worked through)
+  const int spill_blocks = (refr && ctx->queue_spill) ? std::min(kSpillBlocksMax, 2 * (max_depth + 1)) : 0;
+  if (spill_blocks > 0) {
+    const size_t waves = size_t(ctx->n_cus) * RT_WAVES_PER_SIMD * (kBlock / 64);   // the most the kernel is launched with
+    const size_t need = waves * size_t(spill_blocks) * kSpillFields * 64 * sizeof(float);
+    if (need > ctx->spill_bytes) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_spill) RT_HIP(ctx, hipFree(ctx->d_spill));
+      ctx->d_spill = nullptr; ctx->spill_bytes = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_spill, need));
+      ctx->spill_bytes = need;
     }
   }
 
@@ -2121,6 +2242,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   }
   p.defer_output = refr ? 1 : 0;
   p.accum = ctx->d_accum;
+  p.spill = ctx->d_spill; p.spill_blocks = spill_blocks;
   p.camtab = ctx->d_camtab;
   p.vis = ctx->d_vis;
   // tile occupancy: per counter one bit per slot, rounded up to words, plus one word of padding (a claim's
@@ -2308,6 +2430,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_frames) (void)hipFree(ctx->d_frames);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+  if (ctx->d_spill) (void)hipFree(ctx->d_spill);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);
   if (ctx->d_chunk) (void)hipFree(ctx->d_chunk);
   delete ctx;
@@ -2329,6 +2452,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
   }
   if (option == RT_OPT_SPHERE_GRID && (value == 0 || value == 1)) {
     ctx->sphere_grid = value != 0;      // takes effect at the next rt_upload_scene
+    return RT_OK;
+  }
+  if (option == RT_OPT_QUEUE_SPILL && (value == 0 || value == 1)) {
+    ctx->queue_spill = value != 0;      // takes effect at the next render call
     return RT_OK;
   }
   if (option == RT_OPT_OCCLUDER_TABLE && (value == 0 || value == 1)) {

@@ -172,7 +172,7 @@ class Renderer:
     def render_frames(self, cameras, seeds, width, height, samples=1, *,
                       max_depth=_DEFAULT_MAX_DEPTH, rng_mode="keyed", out=None,
                       tile_rows=None, tile_first=0, tile_stride=1):
-        """Animation batch -> uint8 [F, H, W, 3]; up to 256 frames (RT_FRAMES_PER_LAUNCH) share one kernel launch pair.
+        """Animation batch -> uint8 [F, H, W, 3]; up to 1024 frames (RT_FRAMES_PER_LAUNCH) share one kernel launch pair.
 
         With ``tile_rows`` the batch holds only this rank's row tiles of every frame
         (-> uint8 [F, local_rows, W, 3], rt_render_frames_rows)."""
@@ -219,6 +219,11 @@ class Renderer:
         images.  Takes effect at the next upload_scene."""
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_SPHERE_GRID, 1 if on else 0))
         self._options["sphere_grid"] = bool(on)
+
+    def set_queue_spill(self, on: bool):
+        """Refractive scenes: a full work queue sets records aside in device memory (default) or only shrinks
+        its passes; same images up to float summation order."""
+        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_QUEUE_SPILL, 1 if on else 0))
 
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
