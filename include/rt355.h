@@ -95,7 +95,8 @@ int rt_synchronize(rt_ctx* ctx);
  *   at the next rt_upload_scene.
  *   RT_OPT_QUEUE_SPILL: 1 (default) = on refractive scenes a wave of the stream kernel whose work queue
  *   cannot take a full pass's children sets its 64 shallowest records aside in device memory (<= 32 blocks of
- *   3 KB per wave, allocated on first use) instead of shrinking the pass; 0 = shrink only.  Same images to
+ *   3 KB per wave, allocated on first use) instead of shrinking the pass; 0 = shrink only; 2..32 = at most
+ *   that many blocks per wave (tests: a wave whose stack is full shrinks its passes again).  Same images to
  *   float summation order (tests). */
 #define RT_OPT_KERNEL 1
 #define RT_OPT_OCCLUDER_TABLE 2

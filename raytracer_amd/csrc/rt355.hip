@@ -1951,7 +1951,7 @@ struct rt_ctx {
   int grid_dim = 0, grid_n_big = 0;
   float grid_min[3] = {0, 0, 0}, grid_inv_cell[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0};
   bool sphere_grid = true;            // RT_OPT_SPHERE_GRID
-  bool queue_spill = true;            // RT_OPT_QUEUE_SPILL
+  int queue_spill = 1;                // RT_OPT_QUEUE_SPILL: 0 off, 1 automatic depth, 2.. = at most that many blocks per wave
   uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
@@ -2196,7 +2196,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   // refractive scenes: per wave of the stream kernel a stack of 64-record blocks for queue records set aside
   // (a level keeps at most ~128 records waiting while the levels below it are worked through)
-  const int spill_blocks = (refr && ctx->queue_spill) ? std::min(kSpillBlocksMax, 2 * (max_depth + 1)) : 0;
+  const int spill_blocks = (refr && ctx->queue_spill) ? std::min({kSpillBlocksMax, 2 * (max_depth + 1), ctx->queue_spill == 1 ? kSpillBlocksMax : ctx->queue_spill}) : 0;
   if (spill_blocks > 0) {
     const size_t waves = size_t(ctx->n_cus) * RT_WAVES_PER_SIMD * (kBlock / 64);   // the most the kernel is launched with
     const size_t need = waves * size_t(spill_blocks) * kSpillFields * 64 * sizeof(float);
@@ -2454,8 +2454,8 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
     ctx->sphere_grid = value != 0;      // takes effect at the next rt_upload_scene
     return RT_OK;
   }
-  if (option == RT_OPT_QUEUE_SPILL && (value == 0 || value == 1)) {
-    ctx->queue_spill = value != 0;      // takes effect at the next render call
+  if (option == RT_OPT_QUEUE_SPILL && value >= 0 && value <= kSpillBlocksMax) {
+    ctx->queue_spill = value;           // takes effect at the next render call
     return RT_OK;
   }
   if (option == RT_OPT_OCCLUDER_TABLE && (value == 0 || value == 1)) {

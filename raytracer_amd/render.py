@@ -220,10 +220,11 @@ class Renderer:
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_SPHERE_GRID, 1 if on else 0))
         self._options["sphere_grid"] = bool(on)
 
-    def set_queue_spill(self, on: bool):
-        """Refractive scenes: a full work queue sets records aside in device memory (default) or only shrinks
-        its passes; same images up to float summation order."""
-        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_QUEUE_SPILL, 1 if on else 0))
+    def set_queue_spill(self, on):
+        """Refractive scenes: a full work queue sets records aside in device memory (True, default) or only
+        shrinks its passes (False); an int n >= 2 caps the stack at n blocks of 64 records per wave.  Same
+        images up to float summation order."""
+        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_QUEUE_SPILL, int(on)))
 
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
