@@ -208,8 +208,9 @@ def main():
     stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     from raytracer_amd._lib import FRAMES_PER_LAUNCH
-    # (refractive scenes go 256 frames per launch pair: kRefrBatch in csrc/rt355.hip)
-    launches_per_step = -(-F // (min(256, FRAMES_PER_LAUNCH) if packed.has_refraction else FRAMES_PER_LAUNCH)) * args.samples
+    # (refractive scenes: as many frames per launch pair as fit 32 GiB of float pixel sums, kRefrSumBytes in csrc/rt355.hip)
+    per_launch = min(FRAMES_PER_LAUNCH, max(1, (32 << 30) // (12 * rows_max * w))) if packed.has_refraction else FRAMES_PER_LAUNCH
+    launches_per_step = -(-F // per_launch) * args.samples
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
     kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
     if world > 1:

@@ -66,7 +66,7 @@ struct DevLights {
 // frames per launch: the fixed cost of a launch pair (ramp-up, the stream kernel's uneven tail, the
 // gaps between dependent launches: ~0.1 ms) is paid once per batch — 16 -> 64 frames is +14 % on config 2
 constexpr int kMaxBatch = RT_FRAMES_PER_LAUNCH;
-constexpr int kRefrBatch = 256;   // frames per launch pair of a refractive scene (see render_frames)
+constexpr long long kRefrSumBytes = 32ll << 30;   // refractive scenes: most memory the float pixel sums of a launch may take
 struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
 static_assert(kMaxBatch <= 8192, "frame numbers travel in 13 bits of the work-queue records");
 static_assert(RT_MAX_SPHERES <= 4096 && RT_MAX_DEPTH < 127, "object index: 12 bits, level: 7 bits of a record's meta word");
@@ -2174,10 +2174,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // (the kernels count tiles of a batch in 32-bit integers)
   const long long frame_tiles = (long long)(((w.nx + 7) / 8) | 1) * ((w.n_rows + 7) / 8);   // tile ids per frame (odd pitch)
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
-  // refractive scenes add every tree node into a float slab per frame (12 B per pixel): beyond kRefrBatch
-  // frames the slabs' scattered atomics lose more to the caches than the longer launch gains (measured:
-  // glass cubes 39 -> 28 Grays/s at 1024 frames per launch)
-  const int frames_cap = refr ? std::min(kMaxBatch, kRefrBatch) : kMaxBatch;
+  // refractive scenes add every tree node into a float slab per frame (12 B per pixel): a launch holds as many
+  // frames as fit kRefrSumBytes of them (1024 at 1080p, 321 at 4K)
+  const int frames_cap = refr ? int(std::max<long long>(1, std::min<long long>(kMaxBatch, kRefrSumBytes / (12 * std::max<long long>(win_px, 1)))))
+                              : kMaxBatch;
   const int max_batch = int(std::max<long long>(1, std::min<long long>(frames_cap, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
   const int batch = std::min(n_frames, max_batch);
   const bool cubes = ctx->n_cubes > 0;
