@@ -1271,6 +1271,8 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 // ------------------------------------------------------------------------------------------
 constexpr int kBounceCap = 128;                       // <= 63 records when a tile is taken in (<= 64 more); a pass takes 64 and pushes <= 64
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
+constexpr int kQueueFieldsRefr = 12; // refraction: no acc (nodes add into the pixel sums); pixel, meta and key are fields 9..11
+constexpr int queue_fields(bool refr) { return refr ? kQueueFieldsRefr : kQueueFields; }
 #ifndef RT_RING
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
@@ -1289,7 +1291,8 @@ constexpr int kClaimMax = RT_CLAIM;
 constexpr int kBounceCapRefr = 192;                   // refraction: RT_MAX_DEPTH + 2 x 64, see the pass sizing in the kernel
 // Refraction: the fields a record carries (no acc: nodes add into the pixel sums), in the order they are set aside
 constexpr int kSpillFields = 12;
-__host__ __device__ constexpr int spill_field(int k) { return k < 9 ? k : k + 3; }   // 0..8, 12, 13, 14
+__host__ __device__ constexpr int spill_field(int k) { return k; }   // all kQueueFieldsRefr fields of a record
+static_assert(kSpillFields == kQueueFieldsRefr, "a spill block holds whole records");
 constexpr int kSpillBlocksMax = 32;                   // blocks of 64 records a wave may have set aside (3 KB each)
 template <int CAP>
 struct Queue {
@@ -1297,7 +1300,7 @@ struct Queue {
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
 constexpr int wave_lds_bytes(bool refr) {
-  return kQueueFields * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2;
+  return queue_fields(refr) * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2;
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -1371,7 +1374,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   unsigned char* mine = smem + geom_bytes + wave * kWaveLdsBytes;
   Queue<kCap> q{reinterpret_cast<float*>(mine)};
-  int16_t* ring = reinterpret_cast<int16_t*>(mine + kQueueFields * kCap * 4);   // [kRing][kVisTile] tile records
+  int16_t* ring = reinterpret_cast<int16_t*>(mine + queue_fields(REFR) * kCap * 4);   // [kRing][kVisTile] tile records
+  constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : 13, kFKey = REFR ? 11 : 14;   // field numbers
   for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
   if constexpr (CUBES)
     for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
@@ -1557,10 +1561,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             q.at(0, e) = px; q.at(1, e) = py; q.at(2, e) = pz;
             q.at(3, e) = dx; q.at(4, e) = dy; q.at(5, e) = dz;
             q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
-            q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f;        // acc = 0
-            q.at(12, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
-            q.at(13, e) = __uint_as_float(pack_meta(0, frame, idx));
-            q.at(14, e) = __uint_as_float(pixel_key);
+            if constexpr (!REFR) { q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f; }   // acc = 0
+            q.at(kFPixel, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
+            q.at(kFMeta, e) = __uint_as_float(pack_meta(0, frame, idx));
+            q.at(kFKey, e) = __uint_as_float(pixel_key);
           }
           n_bounce += __popcll(mask);
         }
@@ -1598,7 +1602,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         const int high = kCap - p.max_depth;
         if (nb > 0) {
           const bool mine = lane < nb;                               // lane l looks at the l-th record from the top
-          const uint32_t mt = mine ? __float_as_uint(q.at(13, n_bounce - 1 - lane)) : 0u;
+          const uint32_t mt = mine ? __float_as_uint(q.at(kFMeta, n_bounce - 1 - lane)) : 0u;
           const bool pushing = mine && meta_level(mt) < p.max_depth;
           const unsigned long long pm = __ballot(pushing);
           const int upto = lanes_below(pm) + (pushing ? 1 : 0);      // pushing records among the top l + 1
@@ -1627,8 +1631,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       if (lane < nb) {
         px = q.at(0, e); py = q.at(1, e); pz = q.at(2, e);
         dx = q.at(3, e); dy = q.at(4, e); dz = q.at(5, e);
-        meta = __float_as_uint(q.at(13, e));
-        pixel_key = __float_as_uint(q.at(14, e));
+        meta = __float_as_uint(q.at(kFMeta, e));
+        pixel_key = __float_as_uint(q.at(kFKey, e));
       }
       wave_lds_fence();
       const unsigned long long s1 = RT_NOW();
@@ -1638,9 +1642,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       uint32_t wpix = 0;
       auto late_state = [&]() {
         tr = q.at(6, e); tg = q.at(7, e); tb = q.at(8, e);
-        ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e);
-        wpix = __float_as_uint(q.at(12, e));
-        pixel_key = __float_as_uint(q.at(14, e));
+        if constexpr (!REFR) { ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e); }
+        wpix = __float_as_uint(q.at(kFPixel, e));
+        pixel_key = __float_as_uint(q.at(kFKey, e));
       };
       if constexpr (REFR) {
         // ---- refraction in scope (raytracer.py:213-230, :252-254): a hit has up to two children.  With
@@ -1726,18 +1730,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           q.at(0, slot) = rpx; q.at(1, slot) = rpy; q.at(2, slot) = rpz;
           q.at(3, slot) = rdx; q.at(4, slot) = rdy; q.at(5, slot) = rdz;
           q.at(6, slot) = rtr; q.at(7, slot) = rtg; q.at(8, slot) = rtb;
-          q.at(12, slot) = __uint_as_float(wpix);
-          q.at(13, slot) = __uint_as_float(meta_r);
-          q.at(14, slot) = __uint_as_float(pixel_key);
+          q.at(kFPixel, slot) = __uint_as_float(wpix);
+          q.at(kFMeta, slot) = __uint_as_float(meta_r);
+          q.at(kFKey, slot) = __uint_as_float(pixel_key);
         }
         if (push_f && base + __popcll(mask_r) + lanes_below(mask_f) < kCap) {
           const int slot = base + __popcll(mask_r) + lanes_below(mask_f);
           q.at(0, slot) = fpx; q.at(1, slot) = fpy; q.at(2, slot) = fpz;
           q.at(3, slot) = fdx; q.at(4, slot) = fdy; q.at(5, slot) = fdz;
           q.at(6, slot) = ftr; q.at(7, slot) = ftg; q.at(8, slot) = ftb;
-          q.at(12, slot) = __uint_as_float(wpix);
-          q.at(13, slot) = __uint_as_float(meta_f);
-          q.at(14, slot) = __uint_as_float(pixel_key);
+          q.at(kFPixel, slot) = __uint_as_float(wpix);
+          q.at(kFMeta, slot) = __uint_as_float(meta_f);
+          q.at(kFKey, slot) = __uint_as_float(pixel_key);
         }
         n_bounce = min(kCap, base + __popcll(mask_r) + __popcll(mask_f));
         wave_lds_fence();
@@ -1778,9 +1782,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
         q.at(6, slot) = tr; q.at(7, slot) = tg; q.at(8, slot) = tb;
         q.at(9, slot) = ar; q.at(10, slot) = ag; q.at(11, slot) = ab;
-        q.at(12, slot) = __uint_as_float(wpix);
-        q.at(13, slot) = __uint_as_float(meta);
-        q.at(14, slot) = __uint_as_float(pixel_key);
+        q.at(kFPixel, slot) = __uint_as_float(wpix);
+        q.at(kFMeta, slot) = __uint_as_float(meta);
+        q.at(kFKey, slot) = __uint_as_float(pixel_key);
       }
       n_bounce = base + __popcll(mask);
       wave_lds_fence();
