@@ -70,8 +70,15 @@ def test_frames_batch_equals_single_renders(renderer):
     n = _lib.FRAMES_PER_LAUNCH + 6
     cams = [orbit_camera(f) for f in range(n)]
     batch = renderer.render_frames(cams, list(range(n)), 160, 90, 1)
-    for f in (0, 63, 64, n - 1):
+    for f in (0, 63, 64, 255, 256, 700, 1023, 1024, n - 1):     # (frame numbers travel in 13 bits of the queue records)
         assert torch.equal(batch[f], renderer.render(160, 90, 1, camera=cams[f], seed=f))
+    # refractive scene (float pixel sums, resolved per launch): frames beyond 255 of one launch
+    from raytracer_amd.scenes import refractive_scene
+    renderer.upload_scene(refractive_scene())
+    batch = renderer.render_frames(cams[:300], list(range(300)), 160, 90, 1)
+    for f in (0, 255, 256, 299):
+        d = (batch[f].to(torch.int16) - renderer.render(160, 90, 1, camera=cams[f], seed=f).to(torch.int16)).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01
 
 
 def test_8k_frame_runs_and_counts(renderer):
