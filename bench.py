@@ -8,7 +8,8 @@ One "step" = one batch of ``--frames`` (default 1024, = one kernel launch pair) 
 index), inputs (scene) already resident on the GPU.  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
 (tile t -> rank t mod N), each rank renders its tiles of all frames of the batch, and ONE RCCL
-gather per step moves the packed tiles to GPU 0, where rt_scatter_rows puts them in image order:
+gather per step moves the packed tiles (only their non-black 32-byte segments: lossless, see
+raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_scatter_rows puts them in image order:
 total work per step is fixed => "strong" scaling.  Rays are counted by the kernel itself
 (rt_get_ray_counts), not modelled.
 
@@ -160,8 +161,11 @@ def main():
     # N > 1: every rank renders its row tiles of the F frames of a step into a slab; one gather per step
     # moves the slabs to GPU 0, where one launch puts the rows in image order.  Double-buffered: the
     # gather of step i (RCCL's stream) overlaps the render of step i + 1.
+    # Only the 32-byte segments of a slab that are not black travel (lossless, BatchExchange(sparse=True)): the
+    # exchange, not the rays, bounds N > 1.  RT_BENCH_DENSE=1 sends whole slabs.
     ex = BatchExchange(F, slab_bytes, dev,
-                       lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out)) \
+                       lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out),
+                       sparse=not os.environ.get("RT_BENCH_DENSE")) \
         if (world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE")) else None   # (env: rehearse this path on 1 GPU)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -240,11 +244,13 @@ def main():
                                    f"keyed RNG, {n_sph} spheres, 12 area-light samples",
                        "width": w, "height": h, "max_depth": D, "frames_per_step": F,
                        "parallelism": f"row-tiles x{world} (tile {tr} rows) + RCCL gather to GPU 0"
+                                      + (" of the non-black 32-byte segments" if ex is not None and ex.sparse else "")
                        if world > 1 else "single GPU"},
             "rays_per_frame": total_rays / (args.steps * F),
             "rays_per_pixel": total_rays / max(primary, 1.0),
             "mpixels_per_s": primary / dt / 1e6,
             "frames_per_s": args.steps * F / dt,
+            "exchange_bytes_per_step_rank0": (ex.sent_bytes / (args.steps + args.warmup)) if ex is not None else 0,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          # HBM bytes per launch pair: a separate rocprofv3 --pmc pass of this same command

@@ -67,9 +67,18 @@ class BatchExchange:
     ``ex.submit(i)``.  ``ex.drain()`` finishes what is in flight.  ``place(gathered, i)`` runs on the root
     when batch i has arrived (``gathered``: [world, F, slab_bytes]).  Buffers: two slabs per rank, two
     gather buffers on the root.  With ``world == 1`` the slab is handed to ``place`` directly.
-    Works with nccl (GPU tensors) and gloo (CPU tensors; used by the CPU tests of this logic)."""
+    Works with nccl (GPU tensors) and gloo (CPU tensors; used by the CPU tests of this logic).
 
-    def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0):
+    ``sparse=True`` sends only what is not black.  The exchange, not the rays, bounds N > 1 (one GPU renders
+    several times what an xGMI link carries), and most of a frame is sky: every rank keeps the
+    32-byte segments of its slab that hold a non-zero byte (19 % of config 2), the ranks agree on the largest
+    count (one tiny all_gather), and the same fixed-size ``gather`` moves [count_max, 5] int64 rows — segment
+    number + 32 bytes — instead of the slab; the root zero-fills its gather buffer and puts the segments back
+    before ``place`` runs.  Lossless: ``place`` sees the same bytes either way (tests).  Needs the batch's
+    bytes to be a multiple of 32 (else the dense path is used)."""
+
+    def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0,
+                 sparse: bool = False):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
@@ -78,7 +87,9 @@ class BatchExchange:
         self.slabs = [torch.zeros((n_frames, slab_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
         self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
                          for _ in range(2)] if (self.rank == dst and self.world > 1) else [None, None]
-        self.pending = [None, None]      # (work handle, step) of the batch in flight in each buffer
+        self.pending = [None, None]      # (work handle, step[, segments, counts]) of the batch in flight in each buffer
+        self.sparse = bool(sparse) and self.world > 1 and (n_frames * slab_bytes) % 32 == 0
+        self.sent_bytes = 0              # bytes this rank handed to the gather so far (either path)
 
     def slab(self, step: int):
         self._finish(step & 1)           # the batch that used this buffer two steps ago must be gone
@@ -89,6 +100,10 @@ class BatchExchange:
         if self.world == 1:
             self.place(self.slabs[b].unsqueeze(0), step)
             return
+        if self.sparse:
+            self._submit_sparse(step)
+            return
+        self.sent_bytes += self.slabs[b].numel()
         if self.slabs[b].is_cuda and self.dist.get_backend(self.group) == "gloo":
             # rehearsal of the N > 1 path on one GPU (bench.py RT_BENCH_BACKEND=gloo): gloo has no gather for
             # device tensors, so the slabs go through host memory, synchronously
@@ -106,14 +121,59 @@ class BatchExchange:
         self.pending[b] = (work, step)
         self._finish(1 - b)              # the previous batch: its gather overlapped this batch's render
 
+    def _submit_sparse(self, step: int):
+        import torch
+        b = step & 1
+        dist, slab = self.dist, self.slabs[b]
+        staged = slab.is_cuda and dist.get_backend(self.group) == "gloo"   # one-GPU rehearsal: through host memory
+        seg = slab.view(-1).view(torch.int64).view(-1, 4)                  # 32-byte segments
+        nz = (seg != 0).any(1).nonzero().squeeze(1)                        # (waits for the batch to be rendered)
+        n = int(nz.numel())
+        cdev = "cpu" if staged else slab.device
+        mine = torch.tensor([n], dtype=torch.int64, device=cdev)
+        every = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(self.world)]
+        dist.all_gather(every, mine, group=self.group)
+        counts = [int(c) for c in torch.cat(every).tolist()]
+        nmax = max(counts)
+        self.sent_bytes += nmax * 40
+        work = rows = None
+        if nmax:
+            send = torch.empty((nmax, 5), dtype=torch.int64, device=slab.device)
+            send[:n, 0] = nz
+            send[:n, 1:] = seg.index_select(0, nz)
+            if n < nmax:
+                send[n:].zero_()
+            if staged:
+                host = send.cpu()
+                parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+                dist.gather(host, parts, dst=self.dst, group=self.group)
+                if self.rank == self.dst:
+                    rows = torch.stack(parts).to(slab.device)
+            else:
+                if self.rank == self.dst:
+                    rows = torch.empty((self.world, nmax, 5), dtype=torch.int64, device=slab.device)
+                work = dist.gather(send, list(rows.unbind(0)) if self.rank == self.dst else None, dst=self.dst,
+                                   group=self.group, async_op=True)
+        self.pending[b] = (work, step, rows, counts, send if nmax else None)
+        self._finish(1 - b)
+
     def _finish(self, b: int):
         if self.pending[b] is None:
             return
-        work, step = self.pending[b]
+        work, step = self.pending[b][:2]
+        extra = self.pending[b][2:]
         self.pending[b] = None
         if work is not None:
             work.wait()                  # nccl: the current stream waits; gloo: the host does
         if self.rank == self.dst:
+            if extra:                    # sparse: zero-fill, then put every rank's segments back
+                import torch
+                rows, counts = extra[0], extra[1]
+                dense = self.gathered[b].view(self.world, -1).view(torch.int64).view(self.world, -1, 4)
+                dense.zero_()
+                for r, k in enumerate(counts):
+                    if k:
+                        dense[r].index_copy_(0, rows[r, :k, 0], rows[r, :k, 1:])
             self.place(self.gathered[b], step)
 
     def drain(self):

@@ -59,6 +59,45 @@ def test_gather_row_tiles_gloo(world, w, h, tile_rows):
     assert ok and frames_ok and (nonblack or h < 8)
 
 
+def _sparse_exchange_worker(rank, world, port, q):
+    """Mostly black slabs with a different number of lit segments on every rank and step (also none at all)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd.distributed import BatchExchange
+        F, nbytes, steps = 4, 96 * 5, 6
+
+        def slab_of(step, r):
+            g = torch.Generator().manual_seed(1000 * step + r)
+            t = torch.zeros(F * nbytes, dtype=torch.uint8)
+            k = 0 if (step == 2 or (step == 4 and r == 0)) else int(torch.randint(1, 40, (1,), generator=g))
+            pos = torch.randint(0, F * nbytes, (k,), generator=g)
+            t[pos] = torch.randint(1, 256, (k,), generator=g).to(torch.uint8)
+            if step == 5:
+                t[-1] = 7; t[0] = 9          # first and last segment
+            return t.view(F, nbytes)
+
+        placed = []
+
+        def place(gathered, step):
+            exp = torch.stack([slab_of(step, r) for r in range(world)])
+            placed.append((step, bool(torch.equal(gathered, exp))))
+
+        ex = BatchExchange(F, nbytes, "cpu", place, sparse=True)
+        assert ex.sparse
+        for i in range(steps):
+            ex.slab(i).copy_(slab_of(i, rank))
+            ex.submit(i)
+        ex.drain()
+        assert ex.sent_bytes < steps * F * nbytes / 2          # (dense: steps * F * nbytes)
+        assert not BatchExchange(3, 40, "cpu", place, sparse=True).sparse   # 120 bytes: not a multiple of 32 -> dense
+        if rank == 0:
+            q.put(placed)
+    finally:
+        dist.destroy_process_group()
+
+
 def _exchange_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -101,6 +140,22 @@ def test_batch_exchange_pipeline_gloo(world):
     assert [s for s, _ in placed] == list(range(7)) and all(ok for _, ok in placed)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparse_batch_exchange_gloo(world):
+    """BatchExchange(sparse=True): only non-black 32-byte segments travel; the root sees the same bytes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    placed = q.get(timeout=5)
+    assert [s for s, _ in placed] == list(range(6)) and all(ok for _, ok in placed)
+
+
 def test_batch_exchange_single_process():
     from raytracer_amd.distributed import BatchExchange
     seen = []
@@ -112,7 +167,7 @@ def test_batch_exchange_single_process():
     assert seen == [(0, (1, 2, 8), 1), (1, (1, 2, 8), 2), (2, (1, 2, 8), 3)]
 
 
-def _gpu_exchange_worker(rank, world, port, q):
+def _gpu_exchange_worker(rank, world, port, q, sparse=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -121,7 +176,7 @@ def _gpu_exchange_worker(rank, world, port, q):
         from raytracer_amd.distributed import BatchExchange
         from raytracer_amd.render import Renderer
         from raytracer_amd.scenes import generate_scene, orbit_camera
-        w, h, tr, F, steps = 320, 187, 8, 5, 3
+        w, h, tr, F, steps = 320, 187, 8, (4 if sparse else 5), 3     # (sparse: batch bytes a multiple of 32)
         r = Renderer(0)
         r.upload_scene(generate_scene(8, 1, keep_default=True))
         rows_max = tiling.max_local_rows(h, tr, world)
@@ -134,7 +189,8 @@ def _gpu_exchange_worker(rank, world, port, q):
             full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
             ok.append(bool(torch.equal(frames_out, full)))
 
-        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place)
+        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place, sparse=sparse)
+        assert ex.sparse == sparse
         for i in range(steps):
             cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
             r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=ex.slab(i).view(F, rows_max, w, 3),
@@ -149,8 +205,9 @@ def _gpu_exchange_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sparse", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_batch_exchange_of_gpu_row_tiles(world):
+def test_batch_exchange_of_gpu_row_tiles(world, sparse):
     """bench.py's N > 1 step on the GPU: `world` processes (all on cuda:0 here) each render their row tiles
     of a batch with the HIP library, the slabs are gathered (gloo, staged through host memory — RCCL
     needs one GPU per rank) and rank 0 places them with rt_scatter_rows_frames: the assembled frames
@@ -158,7 +215,7 @@ def test_batch_exchange_of_gpu_row_tiles(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_exchange_worker, args=(r, world, port, q, sparse)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
