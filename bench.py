@@ -163,9 +163,14 @@ def main():
     # gather of step i (RCCL's stream) overlaps the render of step i + 1.
     # Only the 32-byte segments of a slab that are not black travel (lossless, BatchExchange(sparse=True)): the
     # exchange, not the rays, bounds N > 1.  RT_BENCH_DENSE=1 sends whole slabs.
+    # The root puts gathered segments straight into image order (segments_to_frames: no dense gather buffer).
+    from raytracer_amd.distributed import segments_to_frames
+    direct = (w * 3) % 32 == 0 and not os.environ.get("RT_BENCH_DENSE_PLACE")
     ex = BatchExchange(F, slab_bytes, dev,
                        lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out),
-                       sparse=not os.environ.get("RT_BENCH_DENSE")) \
+                       sparse=not os.environ.get("RT_BENCH_DENSE"),
+                       place_segments=(lambda rows, counts, i: segments_to_frames(rows, counts, frames_out, w, h, tr, rows_max))
+                       if direct else None) \
         if (world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE")) else None   # (env: rehearse this path on 1 GPU)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]

@@ -78,17 +78,21 @@ class BatchExchange:
     bytes to be a multiple of 32 (else the dense path is used)."""
 
     def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0,
-                 sparse: bool = False):
+                 sparse: bool = False, place_segments=None):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.slabs = [torch.zeros((n_frames, slab_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
-                         for _ in range(2)] if (self.rank == dst and self.world > 1) else [None, None]
-        self.pending = [None, None]      # (work handle, step[, segments, counts]) of the batch in flight in each buffer
         self.sparse = bool(sparse) and self.world > 1 and (n_frames * slab_bytes) % 32 == 0
+        # sparse with ``place_segments(rows, counts, step)``: the root hands the gathered [world, count_max, 5]
+        # segment rows to the caller as they are (see segments_to_frames) and keeps no dense gather buffer
+        self.place_segments = place_segments if self.sparse else None
+        self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
+                         for _ in range(2)] if (self.rank == dst and self.world > 1 and self.place_segments is None) \
+            else [None, None]
+        self.pending = [None, None]      # (work handle, step[, segments, counts]) of the batch in flight in each buffer
         self.sent_bytes = 0              # bytes this rank handed to the gather so far (either path)
 
     def slab(self, step: int):
@@ -166,6 +170,9 @@ class BatchExchange:
         if work is not None:
             work.wait()                  # nccl: the current stream waits; gloo: the host does
         if self.rank == self.dst:
+            if extra and self.place_segments is not None:
+                self.place_segments(extra[0], extra[1], step)
+                return
             if extra:                    # sparse: zero-fill, then put every rank's segments back
                 import torch
                 rows, counts = extra[0], extra[1]
@@ -181,6 +188,29 @@ class BatchExchange:
         order = sorted((p[1], b) for b, p in enumerate(self.pending) if p is not None)
         for _, b in order:
             self._finish(b)
+
+
+def segments_to_frames(rows, counts, frames_out, width: int, height: int, tile_rows: int, rows_max: int):
+    """Root side of the sparse exchange without a dense intermediate: ``rows`` [world, count_max, 5] int64 (segment
+    number within the sender's [F, rows_max, W * 3] slab + its 32 bytes; None when every count is 0) go straight
+    to their place in ``frames_out`` uint8 [F, H, W, 3], which is zero-filled first.  Needs W * 3 % 32 == 0."""
+    import torch
+    world = len(counts)
+    spr = width * 3 // 32                       # segments per image row
+    assert width * 3 % 32 == 0 and frames_out.is_contiguous()
+    out = frames_out.view(-1).view(torch.int64).view(-1, 4)
+    out.zero_()
+    for r, k in enumerate(counts):
+        if not k:
+            continue
+        rowmap = torch.from_numpy(local_rows(height, tile_rows, r, world).astype(np.int64)).to(rows.device)
+        s = rows[r, :k, 0]
+        f = torch.div(s, rows_max * spr, rounding_mode="floor")
+        rem = s - f * (rows_max * spr)
+        lrow = torch.div(rem, spr, rounding_mode="floor")
+        dest = (f * height + rowmap[lrow]) * spr + (rem - lrow * spr)
+        out.index_copy_(0, dest, rows[r, :k, 1:])
+    return frames_out
 
 
 def render_distributed(renderer, width, height, samples=1, *, tile_rows=DEFAULT_TILE_ROWS,

@@ -156,6 +156,34 @@ def test_sparse_batch_exchange_gloo(world):
     assert [s for s, _ in placed] == list(range(6)) and all(ok for _, ok in placed)
 
 
+def test_segments_to_frames_matches_row_placement():
+    """segments_to_frames puts the 32-byte segments of every rank's slab where the dense path's row placement
+    puts the rows (CPU tensors; ragged last tile, ranks with fewer rows than rows_max)."""
+    from raytracer_amd import tiling
+    from raytracer_amd.distributed import segments_to_frames
+    w, h, tr, F = 32, 45, 8, 3
+    for world in (2, 3, 4):
+        rows_max = tiling.max_local_rows(h, tr, world)
+        g = torch.Generator().manual_seed(world)
+        frames = torch.zeros((F, h, w, 3), dtype=torch.uint8)
+        lit = torch.rand((F, h, w), generator=g) < 0.05
+        frames[lit] = torch.randint(1, 256, (int(lit.sum()), 3), generator=g).to(torch.uint8)
+        rows_all, counts = [], []
+        for r in range(world):
+            lr = torch.from_numpy(tiling.local_rows(h, tr, r, world).astype("int64"))
+            slab = torch.zeros((F, rows_max, w * 3), dtype=torch.uint8)
+            slab[:, :len(lr)] = frames[:, lr].reshape(F, len(lr), w * 3)
+            seg = slab.view(-1).view(torch.int64).view(-1, 4)
+            nz = (seg != 0).any(1).nonzero().squeeze(1)
+            rows_all.append(torch.cat([nz[:, None], seg[nz]], 1)); counts.append(len(nz))
+        nmax = max(counts)
+        rows = torch.zeros((world, nmax, 5), dtype=torch.int64)
+        for r in range(world):
+            rows[r, :counts[r]] = rows_all[r]
+        out = torch.full((F, h, w, 3), 77, dtype=torch.uint8)
+        assert torch.equal(segments_to_frames(rows, counts, out, w, h, tr, rows_max), frames)
+
+
 def test_batch_exchange_single_process():
     from raytracer_amd.distributed import BatchExchange
     seen = []
@@ -189,8 +217,16 @@ def _gpu_exchange_worker(rank, world, port, q, sparse=False):
             full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
             ok.append(bool(torch.equal(frames_out, full)))
 
-        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place, sparse=sparse)
-        assert ex.sparse == sparse
+        def place_segments(rows, counts, i):   # sparse, no dense intermediate: segments straight into image order
+            from raytracer_amd.distributed import segments_to_frames
+            segments_to_frames(rows, counts, frames_out, w, h, tr, rows_max)
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
+            ok.append(bool(torch.equal(frames_out, full)))
+
+        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place, sparse=bool(sparse),
+                           place_segments=place_segments if sparse == 2 else None)
+        assert ex.sparse == bool(sparse)
         for i in range(steps):
             cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
             r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=ex.slab(i).view(F, rows_max, w, 3),
@@ -205,7 +241,7 @@ def _gpu_exchange_worker(rank, world, port, q, sparse=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sparse", [False, True])
+@pytest.mark.parametrize("sparse", [0, 1, 2])     # dense / sparse via dense buffer / sparse straight into the frames
 @pytest.mark.parametrize("world", [2, 3])
 def test_batch_exchange_of_gpu_row_tiles(world, sparse):
     """bench.py's N > 1 step on the GPU: `world` processes (all on cuda:0 here) each render their row tiles
