@@ -152,6 +152,8 @@ def main():
     r.set_kernel(args.kernel)
     if os.environ.get("RT_BENCH_NO_SPILL"):     # A/B of the refractive queue's spill stack
         r.set_queue_spill(False)
+    if os.environ.get("RT_BENCH_NO_TILE_FLUSH"):  # A/B of the stream kernel's coalesced output path
+        r.set_tile_flush(False)
 
     rows_max = tiling.max_local_rows(h, tr, world)
     slab_bytes = rows_max * w * 3

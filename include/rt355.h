@@ -97,11 +97,17 @@ int rt_synchronize(rt_ctx* ctx);
  *   cannot take a full pass's children sets its 64 shallowest records aside in device memory (<= 32 blocks of
  *   3 KB per wave, allocated on first use) instead of shrinking the pass; 0 = shrink only; 2..32 = at most
  *   that many blocks per wave (tests: a wave whose stack is full shrinks its passes again).  Same images to
- *   float summation order (tests). */
+ *   float summation order (tests).
+ *   RT_OPT_TILE_FLUSH: 1 (default) = the stream kernel stages the finished pixels of a tile in LDS and stores the
+ *   tile whole (8 x 24 contiguous bytes, whole dwords) when its last pixel is in — the coalesced packed-RGB store
+ *   of the frame (raytracer.py:318, :325); 0 = every finished pixel is stored by itself (three byte stores: one
+ *   memory request per pixel).  Same bytes either way (tests).  Used for 8-bit frames at one sample per pixel of
+ *   scenes without refraction; the other paths store as before. */
 #define RT_OPT_KERNEL 1
 #define RT_OPT_OCCLUDER_TABLE 2
 #define RT_OPT_SPHERE_GRID 3
 #define RT_OPT_QUEUE_SPILL 4
+#define RT_OPT_TILE_FLUSH 5
 #define RT_KERNEL_STREAM 0
 #define RT_KERNEL_PIXEL 1
 int rt_set_option(rt_ctx* ctx, int option, int value);

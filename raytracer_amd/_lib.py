@@ -17,6 +17,7 @@ RT_OPT_KERNEL, RT_KERNEL_STREAM, RT_KERNEL_PIXEL = 1, 0, 1
 RT_OPT_OCCLUDER_TABLE = 2
 RT_OPT_SPHERE_GRID = 3
 RT_OPT_QUEUE_SPILL = 4
+RT_OPT_TILE_FLUSH = 5
 RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT: RT_RNG_CONSTANT,
              "K": RT_RNG_KEYED, "keyed": RT_RNG_KEYED}
 

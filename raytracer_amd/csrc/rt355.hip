@@ -121,6 +121,8 @@ struct RenderParams {
   const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
   int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
+  int tile_flush;        // the stream kernel stores every occupied tile whole (its SLOTS variant): the visibility pass
+                         // writes the pixels of empty tiles only
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
   int16_t* vis;            // [frame][tiles8_y][tiles8_x][kVisTile] per 8x8 tile: 64 primary hit indices (-1 = miss /
                            // outside the window) + header {tx | ty << 16, frame}; visibility pass -> stream kernel
@@ -689,13 +691,32 @@ static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigne
   atomicAdd(&g_dbg[0], (unsigned long long)r); atomicAdd(&g_dbg[1], (unsigned long long)l); atomicAdd(&g_dbg[2], (unsigned long long)i);
 }
 #endif
+// What the shadow rays of one shading point leave behind: unshadowed diffuse / specular weights of the point
+// light and their sums over the area light's samples.  light_colour() turns them into the light colour once
+// the material is at hand — the stream kernel fetches it behind the shadow loops, so that it holds no
+// registers across them.
+struct LightSums {
+  float pd, ps, ad, as;
+};
+__device__ __forceinline__ void light_colour(const DevLights& L, const LightSums& w, float mr, float mg, float mb,
+                                             float spec, float& lr, float& lg, float& lb) {
+  float ps = w.ps, as = w.as;
+  if (!(spec > 0.0f)) { ps = 0.f; as = 0.f; }                        // :191 / :206
+  // :204 + :209 + :189/:194/:196
+  const float inv_ns = 1.0f / float(L.ns);
+  const float pk = L.pint * w.pd, psk = L.pint * spec * ps;
+  const float ak = L.aint * w.ad * inv_ns, ask = L.aint * spec * as * inv_ns;
+  lr = fmaf(mr * L.pcol[0], pk, L.pcol[0] * psk) + L.acol[0] * (ak + ask);
+  lg = fmaf(mg * L.pcol[1], pk, L.pcol[1] * psk) + L.acol[1] * (ak + ask);
+  lb = fmaf(mb * L.pcol[2], pk, L.pcol[2] * psk) + L.acol[2] * (ak + ask);
+}
+
 template <int MODE, int B, bool REFR = false, bool CUBES = false>
-__device__ __forceinline__ void lighting(const DevLights& L, const float4* __restrict__ sg,
+__device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* __restrict__ sg,
                                          const float4* __restrict__ gg, const float2* __restrict__ refr,
                                          const uint32_t* __restrict__ occl_row, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
-                                         float mr, float mg, float mb, float spec, uint32_t level_key,
-                                         float& lr, float& lg, float& lb) {
+                                         uint32_t level_key) {
 #if RT_CULL_STATS
   unsigned dbg_rel_ = 0, dbg_lanes_ = 0, dbg_iters_ = 0;
 #endif
@@ -922,14 +943,7 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
 #if RT_CULL_STATS
   dbg_flush(dbg_rel_, dbg_lanes_, dbg_iters_);
 #endif
-  if (!(spec > 0.0f)) { ps = 0.f; as = 0.f; }                        // :191 / :206
-  // :204 + :209 + :189/:194/:196
-  const float inv_ns = 1.0f / float(L.ns);
-  const float pk = L.pint * pd, psk = L.pint * spec * ps;
-  const float ak = L.aint * ad * inv_ns, ask = L.aint * spec * as * inv_ns;
-  lr = fmaf(mr * L.pcol[0], pk, L.pcol[0] * psk) + L.acol[0] * (ak + ask);
-  lg = fmaf(mg * L.pcol[1], pk, L.pcol[1] * psk) + L.acol[1] * (ak + ask);
-  lb = fmaf(mb * L.pcol[2], pk, L.pcol[2] * psk) + L.acol[2] * (ak + ask);
+  return LightSums{pd, ps, ad, as};
 }
 
 // One shaded hit (trace_ray :240-258 without the recursion): hit point P on sphere `idx`, incoming
@@ -937,28 +951,35 @@ __device__ __forceinline__ void lighting(const DevLights& L, const float4* __res
 //     C_d = (m_d (1-r_d) + r_d C_{d+1}) * l_d   =>   acc += T * m_d (1-r_d) * l_d ;  T *= r_d * l_d
 // and produces the reflection ray (:246-247, direction not renormalised).  Returns true if the
 // path continues (r_d > 0).
-// `load_state` is called after the lighting loops and before T / acc are touched: the stream kernel
-// keeps those (and the other fields lighting does not need) in its LDS record until then, so they
-// do not occupy registers — or scratch — across the 13 x N shadow tests.
-struct NoLateState {
-  __device__ __forceinline__ void operator()() const {}
+// `late.request(idx)` is called before the lighting loops and `late.load(m, spec)` after them, before T / acc
+// are touched: the stream kernel has the material fetched into LDS meanwhile and keeps T, acc and the other
+// fields lighting does not need in its LDS record until then, so they do not occupy registers — or scratch —
+// across the 13 x N shadow tests.
+struct MaterialInRegisters {   // the pixel kernel: plain loads, issued early
+  const RenderParams& p;
+  float4 m;
+  float spec;
+  __device__ __forceinline__ void request(int idx) { m = p.mat[idx]; spec = p.spec[idx]; }
+  __device__ __forceinline__ void load(float4& m_out, float& spec_out) { m_out = m; spec_out = spec; }
 };
-template <int MODE, bool CUBES = false, typename LateState = NoLateState>
+template <int MODE, bool CUBES = false, typename LateState>
 __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* __restrict__ sg, int idx,
                                           float px, float py, float pz, float& dx, float& dy, float& dz,
                                           uint32_t level_key, float& tr, float& tg, float& tb,
                                           float& ar, float& ag, float& ab, float& ox, float& oy,
-                                          float& oz, LateState load_state = LateState()) {
-  const float4 m = p.mat[idx];
-  const float spec = p.spec[idx];
+                                          float& oz, LateState& late) {
+  late.request(idx);
   float nx, ny, nz;
   surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
+  const LightSums w = lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+                               level_key);
+  float4 m;
+  float spec;
+  late.load(m, spec);
   float lr, lg, lb;
-  lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
-                               m.x, m.y, m.z, spec, level_key, lr, lg, lb);
-  load_state();
+  light_colour(p.L, w, m.x, m.y, m.z, spec, lr, lg, lb);
   const float refl = m.w;
   const float keep = 1.0f - refl;                                    // :249
   ar = fmaf(tr * (m.x * keep), lr, ar);
@@ -1065,6 +1086,45 @@ __device__ __forceinline__ void store_tile_rgb(uint8_t* __restrict__ out, const 
       const int r = i / (cols * 3), byte = i - r * (cols * 3), c = byte / 3, ch = byte - 3 * c;
       out[(size_t(row0 + r) * nx + col0) * 3 + byte] = uint8_t(stage[r * TILE_W + c] >> (8 * ch));
     }
+  }
+}
+
+// The kernel's argument block, re-read where it is used.  A persistent kernel that takes RenderParams by value
+// has the compiler load all of it at entry and carry it — ~70 scalar registers — through the whole loop: the
+// stream kernel spilled 148 SGPRs (and, for want of the VGPRs that hold them, 22 VGPRs to scratch) that way.
+// The block lies in the kernarg segment, which is constant memory: params_here() hands out a reference to it
+// whose pointer the compiler cannot see through, so fields are fetched by scalar loads after the call and are
+// dead at the end of the phase that called it.  (The kernel's parameter itself is never touched.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const RenderParams& params_here() {
+  typedef const RenderParams __attribute__((address_space(4)))* kparams_t;
+  kparams_t q = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams is the only kernel argument: offset 0
+  asm volatile("" : "+s"(q));
+  return *(const RenderParams*)q;
+}
+#else   // host pass only parses the kernels
+__device__ __forceinline__ const RenderParams& params_here() { static RenderParams host_never; return host_never; }
+#endif
+
+// One 8x8 tile of packed RGB (render :318, :325 -> the array glTexImage2D takes, :346).  Lane (lane & 7, lane >> 3)
+// holds pixel (col0 + lx, row0 + ly) as an RGBX word.  A full-width tile of a dword-aligned frame leaves as whole
+// dwords: lane l < 48 stores dword w = l % 6 of tile row r = l / 6 — bytes 4w..4w+3 of the row's 24 come from
+// pixels a = 4w / 3 and a + 1 (RGBX words of lanes 8r + a, 8r + a + 1, fetched with ds_bpermute: the LDS
+// crossbar, no LDS memory).  Anything else goes byte by byte.
+__device__ __forceinline__ void store_tile8(uint8_t* __restrict__ out, int nx, int row0, int col0, int rows, int cols,
+                                            int lane, uint32_t rgbx, bool dwords) {
+  if (cols == 8 && dwords) {
+    const int r = (lane * 43) >> 8, w = lane - 6 * r;            // l / 6 for l < 64
+    const int hi3 = w >= 3 ? 1 : 0, a = w + hi3, m = w - 3 * hi3;
+    const int src = (8 * r + a) & 63;
+    const uint32_t lo = __builtin_amdgcn_ds_bpermute(src * 4, int(rgbx));
+    const uint32_t hi = __builtin_amdgcn_ds_bpermute(((src + 1) & 63) * 4, int(rgbx));
+    const unsigned long long six = (unsigned long long)lo | ((unsigned long long)hi << 24);
+    if (lane < 48 && r < rows)
+      *reinterpret_cast<uint32_t*>(out + ((size_t)(row0 + r) * nx + col0) * 3 + size_t(w) * 4) = uint32_t(six >> (8 * m));
+  } else if ((lane & 7) < cols && (lane >> 3) < rows) {
+    uint8_t* o = out + ((size_t)(row0 + (lane >> 3)) * nx + col0 + (lane & 7)) * 3;
+    o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
   }
 }
 
@@ -1188,11 +1248,6 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   uint8_t* out = p.out_rgb + frame_px * 3;
   const bool write_rgb = p.out_rgb && last_sample && !p.defer_output;
   const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
-  // lane l < 48 stores dword w = l % 6 of tile row r = l / 6: bytes 4w..4w+3 of the row's 24 come
-  // from pixels a = 4w / 3 and a + 1 (RGBX words of lanes 8r + a, 8r + a + 1)
-  const int r = (lane * 43) >> 8, w = lane - 6 * r;            // l / 6 for l < 64
-  const int hi3 = w >= 3 ? 1 : 0, a = w + hi3, m = w - 3 * hi3;
-  const int src = (8 * r + a) & 63;
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     if (cols[q] <= 0) break;                                  // wave-uniform: this tile and the ones after it do not exist
@@ -1209,19 +1264,9 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
         atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
       }
     }
-    if (write_rgb) {
-      if (cols[q] == 8 && dwords) {
-        const uint32_t lo = __builtin_amdgcn_ds_bpermute(src * 4, int(rgbx[q]));
-        const uint32_t hi = __builtin_amdgcn_ds_bpermute(((src + 1) & 63) * 4, int(rgbx[q]));
-        const unsigned long long six = (unsigned long long)lo | ((unsigned long long)hi << 24);
-        if (lane < 48 && r < rows)
-          *reinterpret_cast<uint32_t*>(out + ((size_t)(row0 + r) * p.nx + col0 + 8 * q) * 3 + size_t(w) * 4) =
-              uint32_t(six >> (8 * m));
-      } else if (live[q]) {
-        uint8_t* o = out + (wpix0 + 8 * q) * 3;
-        o[0] = uint8_t(rgbx[q]); o[1] = uint8_t(rgbx[q] >> 8); o[2] = uint8_t(rgbx[q] >> 16);
-      }
-    }
+    // (tile_flush: the stream kernel stores an occupied tile whole, its black pixels included)
+    if (write_rgb && !(occupied && p.tile_flush))
+      store_tile8(out, p.nx, row0, col0 + 8 * q, rows, cols[q], lane, rgbx[q], dwords);
   }
 }
 
@@ -1271,8 +1316,25 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 // ------------------------------------------------------------------------------------------
 constexpr int kBounceCap = 128;                       // <= 63 records when a tile is taken in (<= 64 more); a pass takes 64 and pushes <= 64
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
+constexpr int kQueueFieldsSlots = 14; // tile slots: the pixel is a slot and a position in it, part of the meta word
 constexpr int kQueueFieldsRefr = 12; // refraction: no acc (nodes add into the pixel sums); pixel, meta and key are fields 9..11
-constexpr int queue_fields(bool refr) { return refr ? kQueueFieldsRefr : kQueueFields; }
+constexpr int queue_fields(bool refr, bool slots = false) { return refr ? kQueueFieldsRefr : slots ? kQueueFieldsSlots : kQueueFields; }
+// Tile slots (SLOTS variant of the stream kernel): the pixels of a tile leave together.  Finished pixels are
+// staged in LDS, one RGBX word each, in one of kTileSlots records per wave; when the last hit pixel of a tile
+// has finished, the wave stores the tile as the visibility pass stores an empty one (store_tile8: whole dwords,
+// 8 x 24 contiguous bytes).  Scattered 3-byte stores of single pixels cost a fabric write request each
+// (profiles/r1m_c2_*: 3.7e8 requests for 3.9e8 hit pixels per 1024-frame launch, 20 x the bytes they carry).
+#ifndef RT_TILE_SLOTS
+#define RT_TILE_SLOTS 8
+#endif
+constexpr int kTileSlots = RT_TILE_SLOTS;
+static_assert(kTileSlots >= 2 && kTileSlots <= 8, "slot | pixel takes 9 bits of a record's meta word");
+constexpr int kSlotBytes = kTileSlots * (64 * 4 + 4 + 8);   // stage[64] RGBX + pixels left + header {tx | ty << 16, frame}
+// meta word of a SLOTS record: level (7 bits) | slot * 64 + pixel (9 bits) | object (12 bits, from bit 20)
+__device__ __forceinline__ uint32_t pack_meta_slot(int level, int slotpix, int object) {
+  return uint32_t(level) | (uint32_t(slotpix) << 7) | (uint32_t(object) << 20);
+}
+__device__ __forceinline__ int meta_slotpix(uint32_t m) { return int((m >> 7) & 511u); }
 #ifndef RT_RING
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
@@ -1299,8 +1361,8 @@ struct Queue {
   float* f;        // kQueueFields arrays of CAP words (field-major: conflict-free lane access)
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
-constexpr int wave_lds_bytes(bool refr) {
-  return queue_fields(refr) * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2;
+constexpr int wave_lds_bytes(bool refr, bool slots = false) {
+  return queue_fields(refr, slots) * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2 + (slots ? kSlotBytes : 0);
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -1363,26 +1425,39 @@ void queue_take_back(float* qf, const float* src, int at) {
 #define RT_UNLIKELY(x) (x)
 #endif
 
-template <int MODE, bool REFR, bool CUBES, bool GRID = false>
-__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams p) {
+template <int MODE, bool REFR, bool CUBES, bool GRID = false, bool SLOTS = false>
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+  // (the argument block is read through params_here(), phase by phase: never as a whole)
   static_assert(!GRID || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
+  static_assert(!SLOTS || !REFR, "refractive scenes sum tree nodes into `accum`: no tile slots");
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
-  constexpr int kWaveLdsBytes = wave_lds_bytes(REFR);
+  constexpr int kWaveLdsBytes = wave_lds_bytes(REFR, SLOTS);
+  constexpr int kFields = queue_fields(REFR, SLOTS);
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
-  const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  unsigned char* mine = smem + geom_bytes + wave * kWaveLdsBytes;
+  int total_tiles;
+  unsigned char* mine;
+  {
+    const RenderParams& p = params_here();
+    const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
+    mine = smem + geom_bytes + wave * kWaveLdsBytes;
+    for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
+    if constexpr (CUBES)
+      for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
+    const int tiles_per_frame = p.tile_pitch * p.tiles8_y;   // tile ids, padding ids (no record, no occupancy bit) included
+    total_tiles = tiles_per_frame * p.n_frames;
+  }
   Queue<kCap> q{reinterpret_cast<float*>(mine)};
-  int16_t* ring = reinterpret_cast<int16_t*>(mine + queue_fields(REFR) * kCap * 4);   // [kRing][kVisTile] tile records
-  constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : 13, kFKey = REFR ? 11 : 14;   // field numbers
-  for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
-  if constexpr (CUBES)
-    for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
+  int16_t* ring = reinterpret_cast<int16_t*>(mine + kFields * kCap * 4);   // [kRing][kVisTile] tile records
+  // SLOTS: per wave kTileSlots tiles in progress — finished pixels as RGBX words, hit pixels left, header
+  uint32_t* slot_stage = reinterpret_cast<uint32_t*>(mine + kFields * kCap * 4 + kRing * kVisTile * 2);   // [kTileSlots][64]
+  int* slot_left = reinterpret_cast<int*>(slot_stage + kTileSlots * 64);                                    // [kTileSlots]
+  uint32_t* slot_hdr = reinterpret_cast<uint32_t*>(slot_left + kTileSlots);                                 // [kTileSlots][2]
+  uint32_t slot_free = (1u << kTileSlots) - 1u;                                                             // wave-uniform
+  constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : SLOTS ? 12 : 13, kFKey = REFR ? 11 : SLOTS ? 13 : 14;   // field numbers
   __syncthreads();   // the only workgroup-wide synchronisation
 
-  const int tiles_per_frame = p.tile_pitch * p.tiles8_y;   // tile ids, padding ids (no record, no occupancy bit) included
-  const int total_tiles = tiles_per_frame * p.n_frames;
   const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kBlock / 64) + wave);
   const int n_waves = int(gridDim.x) * (kBlock / 64);
   uint32_t n_trace = 0, n_shade = 0;
@@ -1408,6 +1483,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   uint32_t cl_mask = 0u;
   int cl_base = 0;
   if (gwave < total_tiles) {   // (a padding id or an empty tile has no bit)
+    const RenderParams& p = params_here();
     const int slot0 = gwave / kTileCounters;
     cl_mask = (as_const(p.occ)[size_t(hcur) * size_t(p.occ_words) + (slot0 >> 5)] >> (slot0 & 31)) & 1u;
     cl_base = gwave;
@@ -1422,10 +1498,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   uint32_t head = 0, tail = 0;     // tile counts
   bool supply_done = false;
   unsigned long long st_topup = 0, st_wait = 0;
+  unsigned st_passes = 0, st_lanes = 0, st_starved = 0;
 
   // ---- REFR: records set aside in global memory (see the pass sizing below), a stack of 64-record blocks
   int sp_blocks = 0;
   auto sp_block = [&](int b) {   // (derived from the kernel arguments where it is needed: the main loop is short of scalar registers)
+    const RenderParams& p = params_here();
     return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane;
   };
 
@@ -1442,7 +1520,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       }
     }
     // ------------------------------ tile intake ------------------------------------------
-    if (n_bounce < 64 && !done) {
+    // (SLOTS: a tile needs a free slot; with none left the wave shades what it has — a pass frees slots)
+    if (n_bounce < 64 && !done && (!SLOTS || slot_free != 0u)) {
       const unsigned long long s0 = RT_NOW();
       // Take tiles from the ring until a full pass is available, then refill the ring.  Those loads
       // (and the next claim's atomic) fly during the coming pass, so the waits below are normally
@@ -1457,6 +1536,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           // wait for it there anyway: it does not leave a returning atomic's register alone across
           // the pass).
           const unsigned long long t0 = RT_NOW();
+          const RenderParams& p = params_here();
           for (;;) {
             bool asked = false;
             if (!nx_valid && !homeless && __popc(cl_mask) < kRing) {
@@ -1536,7 +1616,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           // the tile becomes a level-0 record on the queue now, with all its lanes at work: the primary
           // ray and its hit point are rebuilt exactly as the visibility pass measured them.
           const int frame = int(m1);
+          const RenderParams& p = params_here();
           const FrameRec fr = as_const(p.frames)[frame];
+          int slotpix = 0;
+          if constexpr (SLOTS) {
+            // the tile's slot: every pixel black until its record finishes (the misses stay so)
+            const int k = __ffs(int(slot_free)) - 1;
+            slot_free &= ~(1u << k);
+            slotpix = k * 64 + lane;
+            slot_stage[slotpix] = 0u;
+            if (lane == 0) { slot_left[k] = __popcll(mask); slot_hdr[2 * k] = m0; slot_hdr[2 * k + 1] = m1; }
+          }
           if (idx >= 0) {
             const rt_camera& cam = fr.cam;
             const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
@@ -1562,13 +1652,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             q.at(3, e) = dx; q.at(4, e) = dy; q.at(5, e) = dz;
             q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
             if constexpr (!REFR) { q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f; }   // acc = 0
-            q.at(kFPixel, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
-            q.at(kFMeta, e) = __uint_as_float(pack_meta(0, frame, idx));
+            if constexpr (SLOTS) {
+              q.at(kFMeta, e) = __uint_as_float(pack_meta_slot(0, slotpix, idx));
+            } else {
+              q.at(kFPixel, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
+              q.at(kFMeta, e) = __uint_as_float(pack_meta(0, frame, idx));
+            }
             q.at(kFKey, e) = __uint_as_float(pixel_key);
           }
           n_bounce += __popcll(mask);
         }
-        if (n_bounce >= 64) consuming = false;               // one more turn: refill, then shade
+        if (n_bounce >= 64 || (SLOTS && slot_free == 0u)) consuming = false;   // one more turn: refill, then shade
       }
       wave_lds_fence();
       st_fetch += RT_NOW() - s0;
@@ -1599,6 +1693,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         // the rule above alone keeps the queue within kCap.
         static_assert(kCap >= RT_MAX_DEPTH + 2 * 64, "a tile's fresh hits must fit below the high-water mark");
         static_assert(kCap <= 3 * 64, "the move below handles three rows of 64 records");
+        const RenderParams& p = params_here();
         const int high = kCap - p.max_depth;
         if (nb > 0) {
           const bool mine = lane < nb;                               // lane l looks at the l-th record from the top
@@ -1643,8 +1738,25 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       auto late_state = [&]() {
         tr = q.at(6, e); tg = q.at(7, e); tb = q.at(8, e);
         if constexpr (!REFR) { ar = q.at(9, e); ag = q.at(10, e); ab = q.at(11, e); }
-        wpix = __float_as_uint(q.at(kFPixel, e));
+        if constexpr (!SLOTS) wpix = __float_as_uint(q.at(kFPixel, e));
         pixel_key = __float_as_uint(q.at(kFKey, e));
+      };
+      // The material of the object a lane shades is fetched BEHIND lighting(), like T and acc (it is needed
+      // only to weight the sums the shadow rays leave): loaded ahead of the shadow loops it held five registers
+      // across them, which have none to spare — it went to scratch and came back, a load of the same latency.
+      struct LateFromRecord {
+        const RenderParams& p;
+        decltype(late_state)& state;
+        const Queue<kCap>& q;
+        int e;
+        __device__ __forceinline__ void request(int) {}
+        __device__ __forceinline__ void load(float4& m, float& spec) {
+          int idx = meta_object(__float_as_uint(q.at(kFMeta, e)));
+          asm volatile("" : "+v"(idx));   // (not the copy taken before the shadow loops: nothing may be hoisted above them)
+          m = p.mat[idx];
+          spec = p.spec[idx];
+          state();
+        }
       };
       if constexpr (REFR) {
         // ---- refraction in scope (raytracer.py:213-230, :252-254): a hit has up to two children.  With
@@ -1657,6 +1769,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         float fpx = 0.f, fpy = 0.f, fpz = 0.f, fdx = 0.f, fdy = 0.f, fdz = 0.f, ftr = 0.f, ftg = 0.f, ftb = 0.f;
         uint32_t meta_r = 0u, meta_f = 0u;
         if (have) {
+          const RenderParams& p = params_here();
           const int level = meta_level(meta), rframe = meta_frame(meta), idx = meta_object(meta);
           ++n_shade;
           const float4 m = p.mat[idx];
@@ -1666,8 +1779,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
           const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
           float lr, lg, lb;
-          lighting<MODE, 1, true, CUBES>(p.L, sg, p.geom, p.refr, nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
-                                  sx, sy, sz, m.x, m.y, m.z, spec, mix(pixel_key, uint32_t(level + 1)), lr, lg, lb);
+          const LightSums lw = lighting<MODE, 1, true, CUBES>(p.L, sg, p.geom, p.refr, nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
+                                  sx, sy, sz, mix(pixel_key, uint32_t(level + 1)));
+          light_colour(p.L, lw, m.x, m.y, m.z, spec, lr, lg, lb);
           late_state();
           s2 = RT_NOW();
           const float refl = m.w, refr = rf.x;
@@ -1750,12 +1864,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         continue;
       }
       if (have) {
-        const int level = meta_level(meta), rframe = meta_frame(meta), idx = meta_object(meta);
+        const int level = meta_level(meta), idx = meta_object(meta);
         ++n_shade;
         float ox, oy, oz;
         const uint32_t level_key = mix(pixel_key, uint32_t(level + 1));
-        bool cont = shade_hit<MODE, CUBES>(p, sg, idx, px, py, pz, dx, dy, dz, level_key,
-                                           tr, tg, tb, ar, ag, ab, ox, oy, oz, late_state);
+        bool cont;
+        {
+          const RenderParams& p = params_here();                     // the lights and tables of lighting(): dead after it
+          LateFromRecord late{p, late_state, q, e};
+          cont = shade_hit<MODE, CUBES>(p, sg, idx, px, py, pz, dx, dy, dz, level_key,
+                                        tr, tg, tb, ar, ag, ab, ox, oy, oz, late);
+        }
+        const RenderParams& p = params_here();
         cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
         s2 = RT_NOW();
         if (cont) {
@@ -1767,12 +1887,22 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           if (idx2 >= 0) {
             again = true;
             hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, dx, dy, dz, t, px, py, pz);
-            meta = pack_meta(level + 1, rframe, idx2);
+            // (the frame / slot and pixel bits of the meta word stay; level and object are replaced)
+            meta = (meta & (SLOTS ? 0x0000FF80u : 0x000FFF80u)) | uint32_t(level + 1) | (uint32_t(idx2) << 20);
           }
         }
-        if (!again)
-          finish_pixel(p, (long long)rframe * p.frame_stride_px + wpix,
-                       (long long)rframe * p.accum_stride_px + wpix, ar, ag, ab, nullptr);
+        if (!again) {
+          if constexpr (SLOTS) {
+            // the pixel waits in its tile's slot; the tile leaves when its last pixel is in (below)
+            const int sp = meta_slotpix(meta);
+            slot_stage[sp] = pack_rgbx(ar, ag, ab);
+            __hip_atomic_fetch_add(slot_left + (sp >> 6), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          } else {
+            const int rframe = meta_frame(meta);
+            finish_pixel(p, (long long)rframe * p.frame_stride_px + wpix,
+                         (long long)rframe * p.accum_stride_px + wpix, ar, ag, ab, nullptr);
+          }
+        }
       }
       wave_lds_fence();   // every lane has its whole record in registers before slots are rewritten
       const unsigned long long mask = __ballot(again);
@@ -1782,18 +1912,48 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         q.at(3, slot) = dx; q.at(4, slot) = dy; q.at(5, slot) = dz;
         q.at(6, slot) = tr; q.at(7, slot) = tg; q.at(8, slot) = tb;
         q.at(9, slot) = ar; q.at(10, slot) = ag; q.at(11, slot) = ab;
-        q.at(kFPixel, slot) = __uint_as_float(wpix);
+        if constexpr (!SLOTS) q.at(kFPixel, slot) = __uint_as_float(wpix);
         q.at(kFMeta, slot) = __uint_as_float(meta);
         q.at(kFKey, slot) = __uint_as_float(pixel_key);
       }
       n_bounce = base + __popcll(mask);
       wave_lds_fence();
+      if constexpr (SLOTS) {
+        // tiles whose last hit pixel finished in this pass leave as whole tiles (render :318, :325)
+        const int left = lane < kTileSlots ? slot_left[lane] : 1;
+        uint32_t complete = uint32_t(__ballot(lane < kTileSlots && left == 0)) & ~slot_free;
+        if (complete != 0u) {
+          const RenderParams& p = params_here();
+          // (the lane's share of a tile store — row, dword, source lanes — is worked out here, from a lane number
+          // the compiler cannot trace: hoisted out of the main loop it would sit in six registers across lighting(),
+          // which has none to spare, and go to scratch and back every pass)
+          int fl = lane;
+          asm volatile("" : "+v"(fl));
+          do {
+            const int k = __ffs(int(complete)) - 1;
+            complete &= complete - 1u;
+            slot_free |= 1u << k;
+            const uint32_t rgbx = slot_stage[k * 64 + fl];
+            const uint32_t m0 = __builtin_amdgcn_readfirstlane(slot_hdr[2 * k]);
+            const uint32_t frame = __builtin_amdgcn_readfirstlane(slot_hdr[2 * k + 1]);
+            const int col0 = int((m0 & 0xFFFFu) * 8u), row0 = int((m0 >> 16) * 8u);
+            uint8_t* out = p.out_rgb + (long long)frame * p.frame_stride_px * 3;
+            const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+            store_tile8(out, p.nx, row0, col0, min(8, p.n_rows - row0), min(8, p.nx - col0), fl, rgbx, dwords);
+          } while (complete != 0u);
+          wave_lds_fence();   // the slots' words are read before an intake reuses them
+        }
+      }
       const unsigned long long s3 = RT_NOW();
       st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
+#if RT_STAMPS
+      st_passes += 1; st_lanes += unsigned(nb); st_starved += (nb < 64 && !done) ? 1u : 0u;
+#endif
     }
   }
 
   // ---- ray statistics (per wave; primaries are the visibility pass's) -----------------------------
+  const RenderParams& p = params_here();
   if (p.counters) {
     unsigned long long tot_t = n_trace, tot_s = n_shade;
 #pragma unroll
@@ -1814,6 +1974,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       atomicAdd(slot + 11, st_light); atomicAdd(slot + 12, st_near); atomicAdd(slot + 13, st_topup);
       atomicAdd(slot + 7, st_wait);
       atomicAdd(slot + 14, RT_NOW() - st_begin); atomicAdd(slot + 15, 1ull);
+      // [4] passes, [5] records shaded in them, [6] passes run short for want of a free tile slot (or of a room in the REFR queue)
+      atomicAdd(slot + 4, (unsigned long long)st_passes); atomicAdd(slot + 5, (unsigned long long)st_lanes);
+      atomicAdd(slot + 6, (unsigned long long)st_starved);
 #endif
     }
   }
@@ -1872,8 +2035,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_pixel_kernel(con
       if (idx < 0) break;                                              // :237-238
       ++n_shade;
       const float px = fmaf(dx, t, ox), py = fmaf(dy, t, oy), pz = fmaf(dz, t, oz);
+      MaterialInRegisters late{p};
       if (!shade_hit<MODE>(p, sg, idx, px, py, pz, dx, dy, dz, mix(pixel_key, uint32_t(level + 1)),
-                           tr, tg, tb, ar, ag, ab, ox, oy, oz))
+                           tr, tg, tb, ar, ag, ab, ox, oy, oz, late))
         break;
     }
     finish_pixel(p, gpix, gpix - frame_px + accum_px, ar, ag, ab, &stage[ly * kTileW + lx]);
@@ -1974,6 +2138,7 @@ struct rt_ctx {
   int n_spheres = -1;
   int kernel = RT_KERNEL_STREAM;
   bool occluder_table = true;    // RT_OPT_OCCLUDER_TABLE: false = every sphere is a candidate for every object
+  bool tile_flush = true;        // RT_OPT_TILE_FLUSH: false = the stream kernel stores finished pixels one by one
   unsigned long long host_primaries = 0;  // primary rays of the visibility pass (one per pixel and sample), counted here
   DevLights lights{};
   std::string err;
@@ -1999,8 +2164,8 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres, bool refr = false) {
-  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr)) * (kBlock / 64);
+size_t stream_lds(int n_spheres, bool refr = false, bool slots = false) {
+  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, slots)) * (kBlock / 64);
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -2133,7 +2298,15 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes) {
   if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true> : rt_visibility_kernel<RT_RNG_KEYED, false>;
   return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false>;
 }
-RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false) {
+RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false, bool slots = false) {
+  if (slots && !refr) {   // finished pixels leave tile by tile (the default for 8-bit frames)
+    if (grid && !cubes)
+      return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true, true>
+                                      : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true, true>;
+    if (rng_mode == RT_RNG_KEYED)
+      return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, false, true> : rt_stream_kernel<RT_RNG_KEYED, false, false, false, true>;
+    return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, false, true> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, false, true>;
+  }
   if (grid && !refr && !cubes)
     return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true>
                                     : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true>;
@@ -2214,6 +2387,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   }
 
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
+  // 8-bit frames at one sample per pixel: the stream kernel stages finished pixels per tile and stores whole tiles
+  const bool slots = stream_kernel && ctx->tile_flush && !refr && samples == 1 && out_rgb && !out_f32;
   if (stream_kernel) {  // primary-hit indices handed from the visibility pass to the stream kernel
     const size_t need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles, odd pitch
     if (need > ctx->vis_elems) {
@@ -2245,6 +2420,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];
   }
   p.defer_output = refr ? 1 : 0;
+  p.tile_flush = slots ? 1 : 0;
   p.accum = ctx->d_accum;
   p.spill = ctx->d_spill; p.spill_blocks = spill_blocks;
   p.camtab = ctx->d_camtab;
@@ -2282,7 +2458,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
-    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr) : pixel_lds(ctx->n_spheres);
+    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = ctx->d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
@@ -2325,7 +2501,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4,
                                    ctx->stream));
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes), vgrid, dim3(kBlock), vlds, ctx->stream, p);
-        hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0), sgrid, dim3(kBlock), lds, ctx->stream, p);
+        hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples)
           hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
                              ctx->stream, p);
@@ -2410,6 +2586,11 @@ int rt_create(int device_id, rt_ctx** out) {
   for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
     if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, true), big)) != hipSuccess)
       return bail(e, "hipFuncSetAttribute");
+  const size_t bigs = stream_lds(RT_MAX_SPHERES, false, true);
+  for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
+    for (int v = 0; v < 3; ++v)   // plain, cubes, grid
+      if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2, true), bigs)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute");
   if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
       (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
@@ -2460,6 +2641,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
   }
   if (option == RT_OPT_QUEUE_SPILL && value >= 0 && value <= kSpillBlocksMax) {
     ctx->queue_spill = value;           // takes effect at the next render call
+    return RT_OK;
+  }
+  if (option == RT_OPT_TILE_FLUSH && (value == 0 || value == 1)) {
+    ctx->tile_flush = value != 0;       // takes effect at the next render call
     return RT_OK;
   }
   if (option == RT_OPT_OCCLUDER_TABLE && (value == 0 || value == 1)) {

@@ -226,6 +226,11 @@ class Renderer:
         images up to float summation order."""
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_QUEUE_SPILL, int(on)))
 
+    def set_tile_flush(self, on: bool):
+        """8-bit frames at one sample per pixel: the stream kernel stores whole tiles from LDS staging (True,
+        default) or every finished pixel by itself (False); same bytes."""
+        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_TILE_FLUSH, 1 if on else 0))
+
     def scatter_rows(self, gathered, n_ranks, width, height, tile_rows, out=None):
         """Root side of the multi-GPU gather: [n_ranks, stride] packed slabs -> image [H, W, 3]."""
         torch = _torch()

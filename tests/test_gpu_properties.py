@@ -305,6 +305,40 @@ def test_queue_spill_changes_only_summation_order(renderer):
         renderer.set_queue_spill(True)
 
 
+def test_tile_flush_changes_no_byte(renderer):
+    """The stream kernel's coalesced output path (finished pixels staged per tile in LDS, whole tiles stored:
+    RT_OPT_TILE_FLUSH, default) writes the bytes the pixel-by-pixel stores write: full frames, ragged sizes
+    (partial edge tiles, widths that are no multiple of 4: the byte path), row tiles whose 8-row tiles straddle,
+    deep bounces (tiles that stay in their slot for many passes), frame batches with a padded frame stride,
+    cubes, many small spheres (sparse tiles: slots run out), both RNG modes."""
+    import torch
+    from raytracer_amd.scenes import cube_scene
+    cases = [(generate_scene(8, 1, keep_default=True), 1920, 1080, 5), (generate_scene(64, 2), 1920, 1080, 8),
+             (default_scene(), 333, 187, 5), (generate_scene(64, 2), 1001, 77, 5), (generate_scene(1024, 3), 960, 540, 5),
+             (generate_scene(300, 7), 640, 360, 5), (cube_scene(), 640, 357, 5), (default_scene(), 5, 3, 5)]
+    try:
+        for scene, w, h, D in cases:
+            out = []
+            for on in (True, False):
+                renderer.set_tile_flush(on)
+                renderer.upload_scene(scene)
+                renderer.reset_ray_counts()
+                frames = [renderer.render(w, h, 1, max_depth=D, rng_mode=mode, seed=9, camera=cam, return_hit_index=True)
+                          for cam, mode in ((None, "K"), (orbit_camera(37, 256), "K"), (None, "C"))]
+                rows = renderer.render_rows(w, h, 1, tile_rows=5, tile_first=1, tile_stride=3, max_depth=D, seed=2)
+                F = 5
+                slab = torch.full((F, h + 3, w, 3), 7, dtype=torch.uint8, device="cuda:0")
+                renderer.render_frames([orbit_camera(f, 64) for f in range(F)], list(range(F)), w, h, 1, max_depth=D, out=slab)
+                out.append((frames, rows, slab, renderer.ray_counts()))
+            (fa, ra, sa, ca), (fb, rb, sb, cb) = out
+            for (a, ha), (b, hb) in zip(fa, fb):
+                assert torch.equal(a, b) and torch.equal(ha, hb)
+            assert torch.equal(ra, rb) and torch.equal(sa, sb) and ca == cb
+            assert int(sa[:, h:].min()) == 7 and int(sa[:, h:].max()) == 7      # rows past the frame stay untouched
+    finally:
+        renderer.set_tile_flush(True)
+
+
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
     pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""

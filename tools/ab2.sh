@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B of library builds with the tile flush on and off: tools/ab2.sh "<workloads>" lib1.so lib2.so ...
+wls=$1; shift
+for lib in "$@"; do
+  for wl in $wls; do
+    for nf in "" 1; do
+    RT_BENCH_NO_TILE_FLUSH=$nf RT355_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --workload $wl 2>&1 | tail -1 | python -c "
+import sys, json
+l=sys.stdin.read().strip()
+try:
+    d=json.loads(l); print('$lib', '$wl', 'flush-off=$nf', 'Mrays/s', round(d['value']), 'kern_ms', round(d['roofline']['kernel_ms'],3))
+except Exception as e: print('$lib $wl ERR', l[-300:])
+"
+    done
+  done
+done

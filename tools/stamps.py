@@ -12,6 +12,8 @@ F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
 r = Renderer(0)
 r.upload_scene(bench.build_scene(wl))
+if os.environ.get("RT_BENCH_NO_TILE_FLUSH"):
+    r.set_tile_flush(False)
 for it in range(2):
     r.reset_ray_counts()
     r.render_frames([Camera()] * F, range(F), w, h, 1, max_depth=D)
@@ -28,4 +30,7 @@ for i, nm in enumerate(names):
     print(f"  {nm:20s} {100.0 * a[8 + i] / max(tot, 1):6.2f} %")
 print(f"  (of intake: vmcnt wait) {100.0 * a[7] / max(tot, 1):6.2f} %")
 print(f"  {'other (setup/store)':20s} {100.0 * (tot - sum(a[8:14])) / max(tot, 1):6.2f} %")
+if not os.environ.get("RT_CULL_STATS"):
+    print(f"passes: {a[4]}, records per pass {a[5] / max(a[4], 1):.2f} of 64, passes run short with tiles left: {100.0 * a[6] / max(a[4], 1):.2f} %")
+    sys.exit(0)
 print(f"culling: {a[4] / max(a[5], 1):.2f} candidate spheres per lane and chunk, drain loop {a[6] / max(a[5], 1):.2f} turns per lane (= wave maximum)")
