@@ -29,6 +29,7 @@ extern "C" {
 #define RT_MAX_AREA_SAMPLES 64   /* AreaLight.samples (raytracer.py:69); the reference uses 12 */
 #define RT_MAX_DEPTH 64          /* upper bound accepted for max_depth                         */
 #define RT_FRAMES_PER_LAUNCH 1024 /* frames of a batch that share one kernel launch pair       */
+#define RT_NOALLOC_SCRATCH_BYTES (24 << 20) /* rt_render_noalloc: device scratch per GPU (frames up to 4K) */
 
 #define RT_OK 0
 #define RT_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned)          */
@@ -164,6 +165,20 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
  *            the reference. */
 int rt_render(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
               int max_depth, int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit);
+
+/* rt_render that allocates nothing.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory — code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, same bytes in out_rgb / out_hit as rt_render, for ONE frame at samples == 1 of a scene without
+ * refractive materials (anything else: RT_EINVAL).  rt_render keeps its tile records, work counters, occupancy
+ * bits, frame record and primary-ray table in buffers it grows with hipMalloc on first use; this entry point keeps
+ * them in a fixed array in device memory instead (RT_NOALLOC_SCRATCH_BYTES = 24 MiB per GPU the library has a
+ * context on, held until the process ends), so it calls no hipMalloc / hipFree / allocating routine.  A frame
+ * whose records do not fit — 2.25 bytes per pixel; 3840x2160 fits — is refused with RT_EINVAL and a message.
+ * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two contexts, or two streams)
+ * race; calls on one stream are ordered.  The scene must have been uploaded before (rt_upload_scene allocates
+ * nothing on the device either, but synchronises). */
+int rt_render_noalloc(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
+                      int max_depth, int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit);
 
 /* Row-tile variant for multi-GPU sharding: renders row tiles t = tile_first, tile_first +
  * tile_stride, ... (tile t covers image rows [t*tile_rows, min((t+1)*tile_rows, height))) and

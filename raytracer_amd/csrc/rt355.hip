@@ -2079,6 +2079,18 @@ thread_local std::string g_last_error;
 
 }  // namespace
 
+// rt_render_noalloc: everything rt_render's kernels keep in device memory besides the frame itself — the frame
+// record, the primary-ray table, the stream kernel's work counters and tile occupancy bits, the visibility
+// pass's tile records — lies in this array instead of buffers grown with hipMalloc.  One copy per GPU, held
+// until the process ends.  Host code never uses the array's name as an address: rt_create asks HIP for the
+// address on its device (hipGetSymbolAddress) and the kernels get that pointer as they get the hipMalloc'ed
+// buffers of the other entry points.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices];   // per device: address of ITS copy of `scratch` (rt_create)
+}
+
 // REFR path: every pixel of the window from its sum over samples and tree nodes in `accum`
 // (render_pixel :297, render :318, :325).
 __global__ __launch_bounds__(256) void rt_resolve_kernel(const RenderParams p) {
@@ -2318,10 +2330,12 @@ RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid =
   return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true> : rt_stream_kernel<RT_RNG_CONSTANT, false, false>;
 }
 
-// Validates, then launches ceil(n_frames / 16) x samples kernels on ctx->stream.
+// Validates, then launches ceil(n_frames / RT_FRAMES_PER_LAUNCH) x samples kernel pairs on ctx->stream.
+// `ws` (rt_render_noalloc): the device's `scratch` array; the call then allocates nothing — its frame record, table,
+// counters and tile records lie there — and fails where it would have had to.
 int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_frames, int width,
            int height, const Window& w, int samples, int max_depth, int rng_mode, uint8_t* out_rgb,
-           float* out_f32, int32_t* out_hit, long long out_frame_stride_px = 0) {
+           float* out_f32, int32_t* out_hit, long long out_frame_stride_px = 0, unsigned char* ws = nullptr) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (ctx->n_spheres < 0) return fail(ctx, RT_ESTATE, "rt_upload_scene has not been called");
   if (!cams || !seeds) return fail(ctx, RT_EINVAL, "camera/seed is NULL");
@@ -2360,6 +2374,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const bool cubes = ctx->n_cubes > 0;
   if ((refr || cubes) && ctx->kernel != RT_KERNEL_STREAM)
     return fail(ctx, RT_ESTATE, "refractive materials and cubes need the default kernel (RT_KERNEL_STREAM)");
+  if (ws && (samples > 1 || refr || n_frames != 1 || ctx->kernel != RT_KERNEL_STREAM))
+    return fail(ctx, RT_EINVAL, "rt_render_noalloc renders one frame at one sample per pixel of a scene without refraction "
+                                "with the default kernel (samples %d, refractive %d): the other cases need buffers "
+                                "that are allocated on demand", samples, int(refr));
   if (samples > 1 || refr) {  // running sums over samples (and tree nodes), one slab per frame of a batch
     const size_t need = size_t(win_px) * 3 * size_t(batch);
     if (need > ctx->accum_floats) {
@@ -2389,8 +2407,9 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   // 8-bit frames at one sample per pixel: the stream kernel stages finished pixels per tile and stores whole tiles
   const bool slots = stream_kernel && ctx->tile_flush && !refr && samples == 1 && out_rgb && !out_f32;
-  if (stream_kernel) {  // primary-hit indices handed from the visibility pass to the stream kernel
-    const size_t need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles, odd pitch
+  const size_t vis_need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles, odd pitch
+  if (stream_kernel && !ws) {  // primary-hit indices handed from the visibility pass to the stream kernel
+    const size_t need = vis_need;
     if (need > ctx->vis_elems) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_vis) RT_HIP(ctx, hipFree(ctx->d_vis));
@@ -2423,14 +2442,17 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.tile_flush = slots ? 1 : 0;
   p.accum = ctx->d_accum;
   p.spill = ctx->d_spill; p.spill_blocks = spill_blocks;
-  p.camtab = ctx->d_camtab;
-  p.vis = ctx->d_vis;
+  FrameRec* d_frames = ctx->d_frames;
+  CamGroup* d_camtab = ctx->d_camtab;
+  int16_t* d_vis = ctx->d_vis;
+  int* d_chunk = ctx->d_chunk;
   // tile occupancy: per counter one bit per slot, rounded up to words, plus one word of padding (a claim's
   // bits are read as two words)
   const long long batch_tiles = frame_tiles * batch;
   const int occ_words = int(((batch_tiles + kTileCounters - 1) / kTileCounters + 31) / 32) + 1;
-  if (stream_kernel) {
-    const size_t need = size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4;
+  const size_t chunk_need = size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4;
+  if (stream_kernel && !ws) {
+    const size_t need = chunk_need;
     if (need > ctx->chunk_bytes) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_chunk) RT_HIP(ctx, hipFree(ctx->d_chunk));
@@ -2438,9 +2460,27 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       RT_HIP(ctx, hipMalloc(&ctx->d_chunk, need));
       ctx->chunk_bytes = need;
     }
+    d_chunk = ctx->d_chunk;
+    d_vis = ctx->d_vis;
   }
-  p.chunk_counter = ctx->d_chunk;
-  p.occ = reinterpret_cast<uint32_t*>(ctx->d_chunk) + kTileCounters * 32;
+  if (ws) {   // rt_render_noalloc: the same buffers, carved out of the device's scratch array (256-byte aligned)
+    auto up = [](size_t n) { return (n + 255) & ~size_t(255); };
+    const size_t o_frames = 0, o_camtab = up(sizeof(FrameRec));
+    const size_t o_chunk = o_camtab + up(sizeof(CamGroup) * size_t(cam_groups_stride(ctx->n_spheres)));
+    const size_t o_vis = o_chunk + up(chunk_need);
+    const size_t total = o_vis + vis_need * sizeof(int16_t);
+    if (total > size_t(RT_NOALLOC_SCRATCH_BYTES))
+      return fail(ctx, RT_EINVAL, "rt_render_noalloc: a %dx%d frame needs %zu bytes of scratch, the library holds %zu "
+                                  "(RT_NOALLOC_SCRATCH_BYTES); use rt_render", w.nx, w.n_rows, total, size_t(RT_NOALLOC_SCRATCH_BYTES));
+    d_frames = reinterpret_cast<FrameRec*>(ws + o_frames);
+    d_camtab = reinterpret_cast<CamGroup*>(ws + o_camtab);
+    d_chunk = reinterpret_cast<int*>(ws + o_chunk);
+    d_vis = reinterpret_cast<int16_t*>(ws + o_vis);
+  }
+  p.camtab = d_camtab;
+  p.vis = d_vis;
+  p.chunk_counter = d_chunk;
+  p.occ = reinterpret_cast<uint32_t*>(d_chunk) + kTileCounters * 32;
   p.occ_words = occ_words;
   p.tiles8_x = (w.nx + 7) / 8; p.tiles8_y = (w.n_rows + 7) / 8;
   p.counters = ctx->d_counters;
@@ -2460,7 +2500,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     const int nf = std::min(max_batch, n_frames - f0);
     const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
-    p.frames = ctx->d_frames;
+    p.frames = d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
       FrameChunk chunk;                              // protects the previous batch's readers)
       const int nc = std::min(kFrameChunk, nf - c0);
@@ -2469,7 +2509,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         chunk.seed[f] = uint32_t(seeds[f0 + c0 + f] ^ (seeds[f0 + c0 + f] >> 32));
       }
       for (int f = nc; f < kFrameChunk; ++f) { chunk.cam[f] = chunk.cam[0]; chunk.seed[f] = 0u; }
-      hipLaunchKernelGGL(rt_store_frames_kernel, dim3(1), dim3(256), 0, ctx->stream, chunk, ctx->d_frames + c0, nc);
+      hipLaunchKernelGGL(rt_store_frames_kernel, dim3(1), dim3(256), 0, ctx->stream, chunk, d_frames + c0, nc);
       RT_HIP(ctx, hipGetLastError());
     }
     p.out_rgb = out_rgb ? out_rgb + size_t(f0) * frame_px * 3 : nullptr;
@@ -2480,7 +2520,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       const int n4 = cam_groups_stride(ctx->n_spheres) * 4;
       {
         hipLaunchKernelGGL(rt_camera_table_kernel, dim3(unsigned((n4 + 255) / 256), unsigned(nf), 1), dim3(256),
-                           0, ctx->stream, (const float4*)ctx->d_geom, ctx->n_spheres, (const FrameRec*)ctx->d_frames, ctx->d_camtab, nf);
+                           0, ctx->stream, (const float4*)ctx->d_geom, ctx->n_spheres, (const FrameRec*)d_frames, d_camtab, nf);
         RT_HIP(ctx, hipGetLastError());
       }
     }
@@ -2498,8 +2538,9 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         const unsigned per_cu = unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
         const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
-        RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk, 0, size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4,
-                                   ctx->stream));
+        // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
+        // keeps the last call's contents)
+        RT_HIP(ctx, hipMemsetAsync(d_chunk, 0, chunk_need, ctx->stream));
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes), vgrid, dim3(kBlock), vlds, ctx->stream, p);
         hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples)
@@ -2555,6 +2596,13 @@ int rt_create(int device_id, rt_ctx** out) {
     return rc;
   };
   if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+  if (device_id < kMaxDevices && !g_scratch_ptr[device_id]) {
+    // this device's copy of the scratch array of rt_render_noalloc (every GPU has its own, at its own address)
+    unsigned char* ptr = nullptr;
+    if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch))) != hipSuccess)
+      return bail(e, "hipGetSymbolAddress(scratch)");
+    g_scratch_ptr[device_id] = ptr;
+  }
   if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
   ctx->stream = ctx->own_stream;
@@ -2818,6 +2866,16 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samp
   if (!out_rgb) return fail(ctx, RT_EINVAL, "out_rgb is NULL");
   Window w{0, width, height, height > 0 ? height : 1, 0, 1, 0};
   return launch(ctx, cam, &seed, 1, width, height, w, samples, max_depth, rng_mode, out_rgb, nullptr, out_hit);
+}
+
+int rt_render_noalloc(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples, int max_depth,
+                      int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit) {
+  if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
+  if (!out_rgb) return fail(ctx, RT_EINVAL, "out_rgb is NULL");
+  unsigned char* ws = (ctx->device >= 0 && ctx->device < kMaxDevices) ? g_scratch_ptr[ctx->device] : nullptr;
+  if (!ws) return fail(ctx, RT_ESTATE, "rt_render_noalloc: no scratch array on device %d", ctx->device);
+  Window w{0, width, height, height > 0 ? height : 1, 0, 1, 0};
+  return launch(ctx, cam, &seed, 1, width, height, w, samples, max_depth, rng_mode, out_rgb, nullptr, out_hit, 0, ws);
 }
 
 static int rows_owned(int height, int tile_rows, int tile_first, int tile_stride) {
