@@ -1329,7 +1329,7 @@ constexpr int queue_fields(bool refr, bool slots = false) { return refr ? kQueue
 #endif
 constexpr int kTileSlots = RT_TILE_SLOTS;
 static_assert(kTileSlots >= 2 && kTileSlots <= 8, "slot | pixel takes 9 bits of a record's meta word");
-constexpr int kSlotBytes = kTileSlots * (64 * 4 + 4 + 8);   // stage[64] RGBX + pixels left + header {tx | ty << 16, frame}
+constexpr int kSlotBytes = kTileSlots * (64 * 4 + 8);       // stage[64] RGBX + header {tx | ty << 16, frame}
 // meta word of a SLOTS record: level (7 bits) | slot * 64 + pixel (9 bits) | object (12 bits, from bit 20)
 __device__ __forceinline__ uint32_t pack_meta_slot(int level, int slotpix, int object) {
   return uint32_t(level) | (uint32_t(slotpix) << 7) | (uint32_t(object) << 20);
@@ -1435,9 +1435,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   constexpr int kFields = queue_fields(REFR, SLOTS);
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The lane number, from a source the compiler cannot trace: every phase of the main loop takes a fresh one, so
+  // that nothing derived from it (LDS addresses of the wave's queue, ring and slots, pixel offsets in a tile) is
+  // carried across lighting() in registers it does not have: such values went to scratch at the top of the kernel
+  // and came back every pass, and the wait for them also waited for the tile loads that are meant to fly.
+  auto lane_here = [&]() { int l = int(threadIdx.x) & 63; asm volatile("" : "+v"(l)); return l; };
   int total_tiles;
-  unsigned char* mine;
+  unsigned char* mine;                                       // wave-uniform
   {
     const RenderParams& p = params_here();
     const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
@@ -1450,11 +1455,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   }
   Queue<kCap> q{reinterpret_cast<float*>(mine)};
   int16_t* ring = reinterpret_cast<int16_t*>(mine + kFields * kCap * 4);   // [kRing][kVisTile] tile records
-  // SLOTS: per wave kTileSlots tiles in progress — finished pixels as RGBX words, hit pixels left, header
+  // SLOTS: per wave kTileSlots tiles in progress — finished pixels as RGBX words and a header in LDS; the number
+  // of hit pixels each still waits for in one byte of a scalar register pair (a tile has at most 64)
   uint32_t* slot_stage = reinterpret_cast<uint32_t*>(mine + kFields * kCap * 4 + kRing * kVisTile * 2);   // [kTileSlots][64]
-  int* slot_left = reinterpret_cast<int*>(slot_stage + kTileSlots * 64);                                    // [kTileSlots]
-  uint32_t* slot_hdr = reinterpret_cast<uint32_t*>(slot_left + kTileSlots);                                 // [kTileSlots][2]
+  uint32_t* slot_hdr = slot_stage + kTileSlots * 64;                                                        // [kTileSlots][2]
   uint32_t slot_free = (1u << kTileSlots) - 1u;                                                             // wave-uniform
+  unsigned long long slot_left = 0ull;                                                                      // byte k: slot k
   constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : SLOTS ? 12 : 13, kFKey = REFR ? 11 : SLOTS ? 13 : 14;   // field numbers
   __syncthreads();   // the only workgroup-wide synchronisation
 
@@ -1504,7 +1510,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   int sp_blocks = 0;
   auto sp_block = [&](int b) {   // (derived from the kernel arguments where it is needed: the main loop is short of scalar registers)
     const RenderParams& p = params_here();
-    return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane;
+    return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane_here();
   };
 
   for (;;) {
@@ -1513,7 +1519,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       // (positions below 128 <= H, like a tile's fresh hits), before any new tile is taken in
       if (RT_UNLIKELY(n_bounce < 64 && sp_blocks > 0)) {
         --sp_blocks;
-        queue_take_back<kCap>(q.f, sp_block(sp_blocks), n_bounce + lane);
+        queue_take_back<kCap>(q.f, sp_block(sp_blocks), n_bounce + lane_here());
         n_bounce += 64;
         wave_lds_fence();
         continue;
@@ -1523,6 +1529,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
     // (SLOTS: a tile needs a free slot; with none left the wave shades what it has — a pass frees slots)
     if (n_bounce < 64 && !done && (!SLOTS || slot_free != 0u)) {
       const unsigned long long s0 = RT_NOW();
+      const int lane = lane_here();
       // Take tiles from the ring until a full pass is available, then refill the ring.  Those loads
       // (and the next claim's atomic) fly during the coming pass, so the waits below are normally
       // free; only when the ring runs empty inside one intake (a run of kRing tiles with few hits)
@@ -1625,7 +1632,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
             slot_free &= ~(1u << k);
             slotpix = k * 64 + lane;
             slot_stage[slotpix] = 0u;
-            if (lane == 0) { slot_left[k] = __popcll(mask); slot_hdr[2 * k] = m0; slot_hdr[2 * k + 1] = m1; }
+            slot_left |= (unsigned long long)__popcll(mask) << (8 * k);      // (the byte is 0: the slot was free)
+            if (lane == 0) { slot_hdr[2 * k] = m0; slot_hdr[2 * k + 1] = m1; }
           }
           if (idx >= 0) {
             const rt_camera& cam = fr.cam;
@@ -1673,6 +1681,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
     // ------------------------------ shading pass -----------------------------------------
     {
       const unsigned long long s0 = RT_NOW();
+      const int lane = lane_here();
       int nb = min(64, n_bounce);                                   // the top records of the queue: lanes [0, nb)
       if constexpr (REFR) {
         // A lane may push TWO records, so the queue can grow; it holds kCap records.  Records are taken
@@ -1720,7 +1729,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       const bool have = lane < nb;
       // Lane l works on record slot e = base + l.  Only what the lighting loops need comes into
       // registers now (P, D, meta, key); T, acc and the pixel stay in the slot until after them.
-      const int e = base + lane;
+      int e = base + lane;
       float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
       uint32_t meta = 0, pixel_key = 0;
       if (lane < nb) {
@@ -1748,11 +1757,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         const RenderParams& p;
         decltype(late_state)& state;
         const Queue<kCap>& q;
-        int e;
+        int& e;
+        uint32_t& meta;
+        int base, lane_now;
         __device__ __forceinline__ void request(int) {}
         __device__ __forceinline__ void load(float4& m, float& spec) {
-          int idx = meta_object(__float_as_uint(q.at(kFMeta, e)));
-          asm volatile("" : "+v"(idx));   // (not the copy taken before the shadow loops: nothing may be hoisted above them)
+          e = base + lane_now;                                   // (a fresh lane number: see lane_here)
+          meta = __float_as_uint(q.at(kFMeta, e));
+          const int idx = meta_object(meta);
           m = p.mat[idx];
           spec = p.spec[idx];
           state();
@@ -1864,18 +1876,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         continue;
       }
       if (have) {
-        const int level = meta_level(meta), idx = meta_object(meta);
         ++n_shade;
         float ox, oy, oz;
-        const uint32_t level_key = mix(pixel_key, uint32_t(level + 1));
         bool cont;
         {
           const RenderParams& p = params_here();                     // the lights and tables of lighting(): dead after it
-          LateFromRecord late{p, late_state, q, e};
-          cont = shade_hit<MODE, CUBES>(p, sg, idx, px, py, pz, dx, dy, dz, level_key,
+          LateFromRecord late{p, late_state, q, e, meta, base, lane_here()};
+          const uint32_t level_key = mix(pixel_key, uint32_t(meta_level(meta) + 1));
+          cont = shade_hit<MODE, CUBES>(p, sg, meta_object(meta), px, py, pz, dx, dy, dz, level_key,
                                         tr, tg, tb, ar, ag, ab, ox, oy, oz, late);
         }
         const RenderParams& p = params_here();
+        const int level = meta_level(meta);                          // (the meta word as re-read behind lighting())
         cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
         s2 = RT_NOW();
         if (cont) {
@@ -1894,9 +1906,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         if (!again) {
           if constexpr (SLOTS) {
             // the pixel waits in its tile's slot; the tile leaves when its last pixel is in (below)
-            const int sp = meta_slotpix(meta);
-            slot_stage[sp] = pack_rgbx(ar, ag, ab);
-            __hip_atomic_fetch_add(slot_left + (sp >> 6), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            slot_stage[meta_slotpix(meta)] = pack_rgbx(ar, ag, ab);
           } else {
             const int rframe = meta_frame(meta);
             finish_pixel(p, (long long)rframe * p.frame_stride_px + wpix,
@@ -1919,16 +1929,26 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       n_bounce = base + __popcll(mask);
       wave_lds_fence();
       if constexpr (SLOTS) {
+        // pixels that finished in this pass, counted per slot: one turn per slot that has some (one to three)
+        uint32_t complete = 0u;
+        {
+          const int fslot = meta_slotpix(meta) >> 6;
+          unsigned long long fin = __ballot(have && !again);
+          while (fin != 0ull) {
+            const int k = __builtin_amdgcn_readlane(fslot, __ffsll((long long)fin) - 1);
+            const unsigned long long same = __ballot(have && !again && fslot == k);
+            fin &= ~same;
+            slot_left -= (unsigned long long)__popcll(same) << (8 * k);
+            if (((slot_left >> (8 * k)) & 0xFFull) == 0ull) complete |= 1u << k;
+          }
+        }
         // tiles whose last hit pixel finished in this pass leave as whole tiles (render :318, :325)
-        const int left = lane < kTileSlots ? slot_left[lane] : 1;
-        uint32_t complete = uint32_t(__ballot(lane < kTileSlots && left == 0)) & ~slot_free;
+        const int fl = lane_here();
         if (complete != 0u) {
           const RenderParams& p = params_here();
           // (the lane's share of a tile store — row, dword, source lanes — is worked out here, from a lane number
           // the compiler cannot trace: hoisted out of the main loop it would sit in six registers across lighting(),
           // which has none to spare, and go to scratch and back every pass)
-          int fl = lane;
-          asm volatile("" : "+v"(fl));
           do {
             const int k = __ffs(int(complete)) - 1;
             complete &= complete - 1u;
@@ -1954,6 +1974,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
 
   // ---- ray statistics (per wave; primaries are the visibility pass's) -----------------------------
   const RenderParams& p = params_here();
+  const int lane = lane_here();
   if (p.counters) {
     unsigned long long tot_t = n_trace, tot_s = n_shade;
 #pragma unroll
