@@ -21,13 +21,15 @@ time, raytracer.py:180,185,248,257,296):
 
 Keyed RNG definition (restated identically in oracle/rt_oracle.cpp and the HIP kernel):
 
-    fmix32(h): h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16
-    mix(h, v) = fmix32(h + 0x9E3779B9 + v)                     (uint32 arithmetic)
-    pixel_key = mix(mix(mix(seed32, x), y), sample)
-    level_key = mix(pixel_key, L)        L = 0 for the two jitter draws of render_pixel,
-                                         L = 1 + logical depth for compute_lighting's draws
-    draw(i)   = (fmix32(level_key + i*0x9E3779B9 + 0x7F4A7C15) >> 8) * 2**-24    in [0, 1)
-    jitter: i = 0 (u), 1 (v);  area-light sample s: i = 2s (random_u), 2s+1 (random_v)
+    fmix32(h): h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16      (uint32 arithmetic)
+    pixel_key = fmix32(seed32 + x*0x9E3779B9 + y*0x85EBCA6B + sample*0xC2B2AE35)
+    level_key = fmix32(pixel_key + 0x9E3779B9 + L)      L = 1 + logical depth, for compute_lighting's draws;
+                                                        the two jitter draws of render_pixel use pixel_key itself
+    pair(key, j) = g(key + j*0x9E3779B9 + 0x7F4A7C15)   g(h): h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16
+    one hash gives TWO draws of 16 bits: (pair >> 16) * 2**-16 and (pair & 0xFFFF) * 2**-16, both in [0, 1)
+    jitter: pair(pixel_key, 0) -> (u draw, v draw);  area-light sample s: pair(level_key, s) -> (random_u, random_v)
+(Round 2 definition: a third of the arithmetic of round 1's one-fmix32-per-24-bit-draw stream, which was a
+quarter of the shading kernel's instructions; every fixture was rendered again by the reference under it.)
 """
 from __future__ import annotations
 
@@ -61,8 +63,23 @@ def mix(h: int, v: int) -> int:
     return fmix32((h + 0x9E3779B9 + v) & M32)
 
 
-def draw_value(level_key: int, i: int) -> float:
-    return (fmix32((level_key + i * 0x9E3779B9 + 0x7F4A7C15) & M32) >> 8) * 2.0 ** -24
+def pixel_key(seed32: int, x: int, y: int, sample: int) -> int:
+    return fmix32((seed32 + x * 0x9E3779B9 + y * 0x85EBCA6B + sample * 0xC2B2AE35) & M32)
+
+
+def pair_hash(key: int, j: int) -> int:
+    h = (key + j * 0x9E3779B9 + 0x7F4A7C15) & M32
+    h = (h * 0x85EBCA6B) & M32
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M32
+    h ^= h >> 16
+    return h
+
+
+def draw_value(key: int, i: int) -> float:
+    """Draw i of the stream `key`: the first (i even) or second (i odd) half of pair i // 2."""
+    h = pair_hash(key, i >> 1)
+    return ((h >> 16) if (i & 1) == 0 else (h & 0xFFFF)) * 2.0 ** -16
 
 
 def fold_seed(seed: int) -> int:
@@ -105,8 +122,8 @@ class _RandomShim:
             level = 0
         if c.mode == "C":
             return 0.5
-        pk = mix(mix(mix(c.seed32, c.x), c.y), c.sample)
-        return draw_value(mix(pk, level), i)
+        pk = pixel_key(c.seed32, c.x, c.y, c.sample)
+        return draw_value(pk if level == 0 else mix(pk, level), i)
 
 
 _REF = None

@@ -58,13 +58,24 @@ inline uint32_t fmix32(uint32_t h) {
   return h;
 }
 inline uint32_t mix(uint32_t h, uint32_t v) { return fmix32(h + 0x9E3779B9u + v); }
+inline uint32_t pixel_key_of(uint32_t seed32, uint32_t x, uint32_t y, uint32_t sample) {
+  return fmix32(seed32 + x * 0x9E3779B9u + y * 0x85EBCA6Bu + sample * 0xC2B2AE35u);
+}
+inline uint32_t pair_hash(uint32_t key, uint32_t j) {
+  uint32_t h = key + j * 0x9E3779B9u + 0x7F4A7C15u;
+  h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
 struct Rng {
   int mode;           // 0 = constant 0.5 (mode C), 1 = keyed (mode K)
   uint32_t pixel_key;
+  // draw i of level `level` (0 = the jitter draws of render_pixel: the pixel's own key): one hash per PAIR of
+  // 16-bit draws
   double draw(uint32_t level, uint32_t i) const {
     if (mode == 0) return 0.5;
-    uint32_t lk = mix(pixel_key, level);
-    return double(fmix32(lk + i * 0x9E3779B9u + 0x7F4A7C15u) >> 8) * (1.0 / 16777216.0);
+    const uint32_t key = level == 0 ? pixel_key : mix(pixel_key, level);
+    const uint32_t h = pair_hash(key, i >> 1);
+    return double((i & 1u) ? (h & 0xFFFFu) : (h >> 16)) * (1.0 / 65536.0);
   }
 };
 
@@ -279,7 +290,7 @@ V3<T> render_pixel(const SceneT<T>& s, int x, int y, int width, int height, int 
   T aspect = T(width) / T(height);                                        // :290
   V3<T> color{0, 0, 0};
   for (int k = 0; k < samples; ++k) {                                     // :292
-    Rng rng{mode, mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(k))};
+    Rng rng{mode, pixel_key_of(seed32, uint32_t(x), uint32_t(y), uint32_t(k))};
     T u = ((T(x) + T(rng.draw(0, 0))) / T(width)) * T(2) - T(1);          // :293
     T v = -((T(y) + T(rng.draw(0, 1))) / T(height) * T(2) - T(1)) / aspect;  // :294
     V3<T> dir = normalize(add(add(muls(s.cam_r, u), muls(s.cam_u, v)), s.cam_f));  // :295

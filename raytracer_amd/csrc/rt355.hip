@@ -179,10 +179,19 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   return h;
 }
 __device__ __forceinline__ uint32_t mix(uint32_t h, uint32_t v) { return fmix32(h + 0x9E3779B9u + v); }
+__device__ __forceinline__ uint32_t pixel_key_of(uint32_t seed32, uint32_t x, uint32_t y, uint32_t sample) {
+  return fmix32(seed32 + x * 0x9E3779B9u + y * 0x85EBCA6Bu + sample * 0xC2B2AE35u);
+}
+// Pair j of the stream `key`: ONE hash (two multiplies) gives two 16-bit draws, returned as 1 + draw in [1, 2) —
+// the 16 bits go straight into a float's mantissa (shift, and-or: no half-rate integer conversion), and
+// `r - 1.5f` / `r - 1.0f` are exact, so the values are those of (h >> 16) * 2^-16 and (h & 0xFFFF) * 2^-16.
 template <int MODE>
-__device__ __forceinline__ float draw(uint32_t level_key, uint32_t i) {
-  if (MODE == RT_RNG_CONSTANT) return 0.5f;
-  return float(fmix32(level_key + i * 0x9E3779B9u + 0x7F4A7C15u) >> 8) * (1.0f / 16777216.0f);
+__device__ __forceinline__ void draw_pair1(uint32_t key, uint32_t j, float& first1, float& second1) {
+  if (MODE == RT_RNG_CONSTANT) { first1 = 1.5f; second1 = 1.5f; return; }
+  uint32_t h = key + j * 0x9E3779B9u + 0x7F4A7C15u;
+  h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  first1 = __uint_as_float(((h >> 9) & 0x007FFF80u) | 0x3F800000u);
+  second1 = __uint_as_float(((h << 7) & 0x007FFF80u) | 0x3F800000u);
 }
 
 // 1-ulp hardware reciprocal / reciprocal square root / square root (v_rcp_f32, v_rsq_f32,
@@ -733,8 +742,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       if (j == 0) {  // scene['global_light'] (:198)
         lx = L.ppos[0]; ly = L.ppos[1]; lz = L.ppos[2];
       } else {       // area-light sample j-1 (:180-182)
-        const float ru = draw<MODE>(level_key, uint32_t(2 * (j - 1))) - 0.5f;
-        const float rv = draw<MODE>(level_key, uint32_t(2 * (j - 1) + 1)) - 0.5f;
+        float ru1, rv1;
+        draw_pair1<MODE>(level_key, uint32_t(j - 1), ru1, rv1);
+        const float ru = ru1 - 1.5f, rv = rv1 - 1.5f;                 // random.random() - 0.5
         lx = fmaf(L.av[0], rv, fmaf(L.au[0], ru, L.apos[0]));
         ly = fmaf(L.av[1], rv, fmaf(L.au[1], ru, L.apos[1]));
         lz = fmaf(L.av[2], rv, fmaf(L.au[2], ru, L.apos[2]));
@@ -1003,10 +1013,11 @@ __device__ __forceinline__ void primary_ray(const RenderParams& p, const rt_came
   // paths amplify that 3e-8 by ~10x per bounce (tests: facing mirrors).  1/aspect is a multiply.
   const float fw = float(p.width), fh = float(p.height);
   const float inv_aspect = p.inv_aspect;                                                      // :290
-  pixel_key = mix(mix(mix(seed32, uint32_t(x)), uint32_t(y)), uint32_t(sidx));
-  const uint32_t jk = mix(pixel_key, 0u);
-  const float u = div_exact(float(x) + draw<MODE>(jk, 0u), fw, p.inv_w) * 2.0f - 1.0f;                  // :293
-  const float v = -(div_exact(float(y) + draw<MODE>(jk, 1u), fh, p.inv_h) * 2.0f - 1.0f) * inv_aspect;  // :294
+  pixel_key = pixel_key_of(seed32, uint32_t(x), uint32_t(y), uint32_t(sidx));
+  float ju1, jv1;
+  draw_pair1<MODE>(pixel_key, 0u, ju1, jv1);                    // the two jitter draws: the pixel's own stream
+  const float u = div_exact(float(x) + (ju1 - 1.0f), fw, p.inv_w) * 2.0f - 1.0f;                  // :293
+  const float v = -(div_exact(float(y) + (jv1 - 1.0f), fh, p.inv_h) * 2.0f - 1.0f) * inv_aspect;  // :294
   dx = fmaf(cam.up[0], v, cam.right[0] * u) + cam.forward[0];
   dy = fmaf(cam.up[1], v, cam.right[1] * u) + cam.forward[1];
   dz = fmaf(cam.up[2], v, cam.right[2] * u) + cam.forward[2];
