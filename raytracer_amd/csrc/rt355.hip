@@ -123,6 +123,9 @@ struct RenderParams {
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
   int tile_flush;        // the stream kernel stores every occupied tile whole (its SLOTS variant): the visibility pass
                          // writes the pixels of empty tiles only
+  long long vis_sample_stride;  // all samples shaded by one stream-kernel launch (the kernels' MULTI variants): elements
+                                // between the tile records of consecutive samples of the batch (sample-major: sample 0's first)
+  unsigned long long* present;  // MULTI: [tile ids of the batch] bit s: sample s of the tile hit something (zeroed per batch)
   const CamGroup* camtab;  // [frame][n4 / 4] primary_hit tables
   int16_t* vis;            // [frame][tiles8_y][tiles8_x][kVisTile] per 8x8 tile: 64 primary hit indices (-1 = miss /
                            // outside the window) + header {tx | ty << 16, frame}; visibility pass -> stream kernel
@@ -1152,7 +1155,7 @@ __device__ __forceinline__ void store_tile8(uint8_t* __restrict__ out, int nx, i
 // profiles/r1_ubench_issue_mix.txt), so it has no LDS staging, no barrier and no per-lane divisions:
 // the packed RGB rows of a tile (24 B each) are assembled across lanes with ds_bpermute.
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool CUBES>
+template <int MODE, bool CUBES, bool MULTI = false>
 __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
   // a wave covers kVisTiles 8x8 tiles side by side: lane (lx, ly) traces pixel (lx, ly) of each
   constexpr int NT = kVisTiles;
@@ -1248,8 +1251,9 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     for (int q = 0; q < NT; ++q) {
       if (!live[q]) idx[q] = -1;
       if (live[q] && p.out_hit && last_sample) p.out_hit[frame_px + wpix0 + 8 * q] = idx[q];
-      if (live[q] && idx[q] < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
-        finish_pixel(p, frame_px + wpix0 + 8 * q, accum_px + wpix0 + 8 * q, 0.f, 0.f, 0.f, &rgbx[q]);
+      if constexpr (!MULTI)
+        if (live[q] && idx[q] < 0 && !p.defer_output)   // :237-238 miss -> black (resolves the running mean over samples too)
+          finish_pixel(p, frame_px + wpix0 + 8 * q, accum_px + wpix0 + 8 * q, 0.f, 0.f, 0.f, &rgbx[q]);
     }
   }
   // tile-major hand-over: the 64 indices of a tile are 128 contiguous bytes; lanes outside the
@@ -1259,21 +1263,52 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   uint8_t* out = p.out_rgb + frame_px * 3;
   const bool write_rgb = p.out_rgb && last_sample && !p.defer_output;
   const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+  const uint32_t id0 = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
+                       uint32_t(col0 >> 3);               // tile id of the wave's first tile; the others follow
+  // MULTI (2..64 samples, all shaded by ONE stream-kernel launch): this launch traces sample p.sample_index of every
+  // pixel.  A sample's hits go into the sample's own tile records; which samples of a tile hit anything is collected
+  // in `present` (64 bits per tile, zeroed per batch), and the launch of the LAST sample, which sees all the others'
+  // bits, completes sample 0's record — the one the stream kernel's tile supply loads — with a header that lists
+  // them, sets the occupancy bit, and writes the pixels of tiles that no sample hit.
+  unsigned long long before[NT];
+  if constexpr (MULTI) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) before[q] = 0ull;
+    if (last_sample) {
+      const unsigned long long* pr = p.present + id0;      // (earlier launches' atomics: visible across the kernel boundary)
+#pragma unroll
+      for (int q = 0; q < NT; ++q) if (cols[q] > 0) before[q] = pr[q];
+    }
+  }
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     if (cols[q] <= 0) break;                                  // wave-uniform: this tile and the ones after it do not exist
     // (a tile without a hit gets no record and no occupancy bit: the stream kernel never looks at it)
-    const bool occupied = __ballot(idx[q] >= 0) != 0ull;
-    if (occupied) rec[q * kVisTile + lane] = int16_t(idx[q]);
-    if (occupied && lane == 0) {
-      *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
-          make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
-      {   // tile id = slot * kTileCounters + counter (see the stream kernel's tile supply)
-        const uint32_t id = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
-                            uint32_t(col0 >> 3) + uint32_t(q);
-        const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
-        atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
+    const bool hit_now = __ballot(idx[q] >= 0) != 0ull;
+    bool occupied = hit_now;
+    if constexpr (MULTI) {
+      int16_t* rec_s = rec + (size_t)p.sample_index * (size_t)p.vis_sample_stride;
+      if (hit_now) rec_s[q * kVisTile + lane] = int16_t(idx[q]);
+      if (!last_sample) {
+        if (hit_now && lane == 0) atomicOr(p.present + id0 + q, 1ull << p.sample_index);   // no return value
+        continue;
       }
+      const unsigned long long all = before[q] | (hit_now ? 1ull << p.sample_index : 0ull);
+      occupied = all != 0ull;
+      if (occupied && !(all & 1ull)) rec[q * kVisTile + lane] = int16_t(-1);   // sample 0 hit nothing: its record says so
+      if (occupied && lane == 0)
+        *reinterpret_cast<uint4*>(rec + q * kVisTile + 64) =
+            make_uint4(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame), uint32_t(all), uint32_t(all >> 32));
+    } else {
+      if (occupied) rec[q * kVisTile + lane] = int16_t(idx[q]);
+      if (occupied && lane == 0)
+        *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
+            make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
+    }
+    if (occupied && lane == 0) {   // tile id = slot * kTileCounters + counter (see the stream kernel's tile supply)
+      const uint32_t id = id0 + uint32_t(q);
+      const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
+      atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
     }
     // (tile_flush: the stream kernel stores an occupied tile whole, its black pixels included)
     if (write_rgb && !(occupied && p.tile_flush))
@@ -1329,7 +1364,7 @@ constexpr int kBounceCap = 128;                       // <= 63 records when a ti
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
 constexpr int kQueueFieldsSlots = 14; // tile slots: the pixel is a slot and a position in it, part of the meta word
 constexpr int kQueueFieldsRefr = 12; // refraction: no acc (nodes add into the pixel sums); pixel, meta and key are fields 9..11
-constexpr int queue_fields(bool refr, bool slots = false) { return refr ? kQueueFieldsRefr : slots ? kQueueFieldsSlots : kQueueFields; }
+constexpr int queue_fields(bool refr, int out = 0) { return refr ? kQueueFieldsRefr : out ? kQueueFieldsSlots : kQueueFields; }
 // Tile slots (SLOTS variant of the stream kernel): the pixels of a tile leave together.  Finished pixels are
 // staged in LDS, one RGBX word each, in one of kTileSlots records per wave; when the last hit pixel of a tile
 // has finished, the wave stores the tile as the visibility pass stores an empty one (store_tile8: whole dwords,
@@ -1340,7 +1375,20 @@ constexpr int queue_fields(bool refr, bool slots = false) { return refr ? kQueue
 #endif
 constexpr int kTileSlots = RT_TILE_SLOTS;
 static_assert(kTileSlots >= 2 && kTileSlots <= 8, "slot | pixel takes 9 bits of a record's meta word");
-constexpr int kSlotBytes = kTileSlots * (64 * 4 + 8);       // stage[64] RGBX + header {tx | ty << 16, frame}
+// All samples of a pixel in one launch pair (MULTI, 2..64 samples, render_pixel :292-297): a slot sums its
+// tile's samples in LDS as three floats per pixel and takes them ONE AFTER ANOTHER, in sample order — the sum
+// is the one the per-sample launches form in `accum`, to the last bit — while other slots keep the passes full.
+// It holds the tile record of its next sample (prefetched) besides.
+#ifndef RT_TILE_SLOTS_MULTI
+#define RT_TILE_SLOTS_MULTI 6
+#endif
+constexpr int kTileSlotsMulti = RT_TILE_SLOTS_MULTI;
+static_assert(kTileSlotsMulti >= 2 && kTileSlotsMulti <= 8, "slot | pixel takes 9 bits of a record's meta word");
+constexpr int kSlotHdr = 4;                                 // words: tx | ty << 16, frame, samples still to take (64 bits)
+constexpr int tile_slots(int out) { return out == 2 ? kTileSlotsMulti : kTileSlots; }
+constexpr int slot_bytes(int out) {     // per wave: stage (RGBX words, or 3 float sums per pixel) + header (+ next record)
+  return out == 0 ? 0 : out == 1 ? kTileSlots * (64 * 4 + kSlotHdr * 4) : kTileSlotsMulti * (3 * 64 * 4 + kSlotHdr * 4 + 72 * 2);
+}
 // meta word of a SLOTS record: level (7 bits) | slot * 64 + pixel (9 bits) | object (12 bits, from bit 20)
 __device__ __forceinline__ uint32_t pack_meta_slot(int level, int slotpix, int object) {
   return uint32_t(level) | (uint32_t(slotpix) << 7) | (uint32_t(object) << 20);
@@ -1372,8 +1420,8 @@ struct Queue {
   float* f;        // kQueueFields arrays of CAP words (field-major: conflict-free lane access)
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
-constexpr int wave_lds_bytes(bool refr, bool slots = false) {
-  return queue_fields(refr, slots) * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2 + (slots ? kSlotBytes : 0);
+constexpr int wave_lds_bytes(bool refr, int out = 0) {
+  return queue_fields(refr, out) * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2 + slot_bytes(out);
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -1436,14 +1484,18 @@ void queue_take_back(float* qf, const float* src, int at) {
 #define RT_UNLIKELY(x) (x)
 #endif
 
-template <int MODE, bool REFR, bool CUBES, bool GRID = false, bool SLOTS = false>
-__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+// OUT: how finished pixels leave — 0: one by one (float / multi-sample / refraction paths), 1: whole tiles from
+// RGBX staging in per-wave tile slots, 2: the same with all samples of a pixel summed in the slot (MULTI)
+template <int MODE, bool REFR, bool CUBES, bool GRID = false, int OUT = 0>
+__global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
   // (the argument block is read through params_here(), phase by phase: never as a whole)
+  constexpr bool SLOTS = OUT != 0, MULTI = OUT == 2;
   static_assert(!GRID || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
   static_assert(!SLOTS || !REFR, "refractive scenes sum tree nodes into `accum`: no tile slots");
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
-  constexpr int kWaveLdsBytes = wave_lds_bytes(REFR, SLOTS);
-  constexpr int kFields = queue_fields(REFR, SLOTS);
+  constexpr int kWaveLdsBytes = wave_lds_bytes(REFR, OUT);
+  constexpr int kFields = queue_fields(REFR, OUT);
+  constexpr int kSlots = tile_slots(OUT);
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1468,10 +1520,13 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
   int16_t* ring = reinterpret_cast<int16_t*>(mine + kFields * kCap * 4);   // [kRing][kVisTile] tile records
   // SLOTS: per wave kTileSlots tiles in progress — finished pixels as RGBX words and a header in LDS; the number
   // of hit pixels each still waits for in one byte of a scalar register pair (a tile has at most 64)
-  uint32_t* slot_stage = reinterpret_cast<uint32_t*>(mine + kFields * kCap * 4 + kRing * kVisTile * 2);   // [kTileSlots][64]
-  uint32_t* slot_hdr = slot_stage + kTileSlots * 64;                                                        // [kTileSlots][2]
-  uint32_t slot_free = (1u << kTileSlots) - 1u;                                                             // wave-uniform
+  uint32_t* slot_stage = reinterpret_cast<uint32_t*>(mine + kFields * kCap * 4 + kRing * kVisTile * 2);   // [kSlots][64] RGBX
+  float* slot_sum = reinterpret_cast<float*>(slot_stage);                                                   // MULTI: [kSlots][3][64]
+  uint32_t* slot_hdr = slot_stage + kSlots * 64 * (MULTI ? 3 : 1);                                          // [kSlots][kSlotHdr]
+  int16_t* slot_next = reinterpret_cast<int16_t*>(slot_hdr + kSlots * kSlotHdr);                            // MULTI: [kSlots][kVisTile]
+  uint32_t slot_free = (1u << kSlots) - 1u;                                                                 // wave-uniform
   unsigned long long slot_left = 0ull;                                                                      // byte k: slot k
+  uint32_t slot_ready = 0u;       // MULTI: slots whose current sample is finished and that have another to take in
   constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : SLOTS ? 12 : 13, kFKey = REFR ? 11 : SLOTS ? 13 : 14;   // field numbers
   __syncthreads();   // the only workgroup-wide synchronisation
 
@@ -1524,6 +1579,64 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
     return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane_here();
   };
 
+  // ---- a tile's hit pixels (one sample of them) become level-0 records on the queue.  The tile's frame is
+  // wave-uniform: its camera and seed come by scalar load; every hit pixel rebuilds its primary ray and hit
+  // point exactly as the visibility pass measured them, with all lanes of the tile at work.
+  auto take_in = [&](int idx, unsigned long long mask, uint32_t m0, uint32_t m1, int sample, int k) {
+    const int lane = lane_here();
+    const RenderParams& p = params_here();
+    const int col = int((m0 & 0xFFFFu) * 8u) + (lane & 7), row = int((m0 >> 16) * 8u) + (lane >> 3);
+    const int frame = int(m1);
+    const FrameRec fr = as_const(p.frames)[frame];
+    const int slotpix = k * 64 + lane;
+    if constexpr (SLOTS) slot_left |= (unsigned long long)__popcll(mask) << (8 * k);      // (the byte is 0 now)
+    if (idx >= 0) {
+      const rt_camera& cam = fr.cam;
+      const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
+      uint32_t pixel_key;
+      float dx, dy, dz, px, py, pz;
+      primary_ray<MODE>(p, cam, fr.seed, p.x0 + col, y, MULTI ? sample : p.sample_index, pixel_key, dx, dy, dz);
+      if (CUBES && idx >= p.n_spheres) {
+        float t = 0.f;
+        int face = 0;
+        const int c = idx - p.n_spheres;
+        cube_t(sg[p.n_spheres + 2 * c], sg[p.n_spheres + 2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2],
+               dx, dy, dz, frcp(dx), frcp(dy), frcp(dz), t, face);
+        hit_point<CUBES>(sg, p.n_spheres, idx, face, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t,
+                         px, py, pz);                                                                        // :168
+      } else {
+        const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        float dl;
+        const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
+        px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
+      }
+      const int e = n_bounce + lanes_below(mask);
+      q.at(0, e) = px; q.at(1, e) = py; q.at(2, e) = pz;
+      q.at(3, e) = dx; q.at(4, e) = dy; q.at(5, e) = dz;
+      q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
+      if constexpr (!REFR) { q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f; }   // acc = 0
+      if constexpr (SLOTS) {
+        q.at(kFMeta, e) = __uint_as_float(pack_meta_slot(0, slotpix, idx));
+      } else {
+        q.at(kFPixel, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
+        q.at(kFMeta, e) = __uint_as_float(pack_meta(0, frame, idx));
+      }
+      q.at(kFKey, e) = __uint_as_float(pixel_key);
+    }
+    n_bounce += __popcll(mask);
+  };
+  // MULTI: the record of sample `sample` of the tile in slot k is requested into the slot (36 lanes x 4 bytes,
+  // LDS-direct): it lands while the slot's current sample is shaded
+  auto request_next = [&](int k, uint32_t m0, uint32_t m1, int sample) {
+    const int lane = lane_here();
+    const RenderParams& p = params_here();
+    const size_t id = size_t(m1) * size_t(p.tile_pitch * p.tiles8_y) + size_t(m0 >> 16) * size_t(p.tile_pitch) + size_t(m0 & 0xFFFFu);
+    if (lane < kVisTile / 2 && sample < p.n_samples)   // (the second test only keeps a damaged header from becoming a stray load)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(p.vis + size_t(sample) * size_t(p.vis_sample_stride) + id * kVisTile + lane * 2),
+          (__attribute__((address_space(3))) void*)(slot_next + k * kVisTile), 4, 0, 0);
+  };
+
   for (;;) {
     if constexpr (REFR) {
       // fewer than a pass's worth of records in LDS and a block set aside: it comes back, on top of the queue
@@ -1537,6 +1650,28 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
       }
     }
     // ------------------------------ tile intake ------------------------------------------
+    if constexpr (MULTI) {
+      // slots whose sample is finished take in their next one first (they hold LDS that new tiles wait for)
+      while (n_bounce < 64 && slot_ready != 0u) {
+        const int lane = lane_here();
+        const int k = __ffs(int(slot_ready)) - 1;
+        slot_ready &= ~(1u << k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record requested when the previous sample came in
+        const int idx = slot_next[k * kVisTile + lane];
+        const unsigned long long mask = __ballot(idx >= 0);
+        const uint32_t m0 = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k]);
+        const uint32_t m1 = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 1]);
+        unsigned long long todo = ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 3])) << 32) |
+                                  (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 2]));
+        const int sample = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        wave_lds_fence();                                  // the record is in registers before the next one may land on it
+        if (lane == 0) { slot_hdr[kSlotHdr * k + 2] = uint32_t(todo); slot_hdr[kSlotHdr * k + 3] = uint32_t(todo >> 32); }
+        if (todo != 0ull) request_next(k, m0, m1, __ffsll((long long)todo) - 1);
+        take_in(idx, mask, m0, m1, sample, k);
+        wave_lds_fence();
+      }
+    }
     // (SLOTS: a tile needs a free slot; with none left the wave shades what it has — a pass frees slots)
     if (n_bounce < 64 && !done && (!SLOTS || slot_free != 0u)) {
       const unsigned long long s0 = RT_NOW();
@@ -1626,60 +1761,35 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
         ++head;
         const int idx = ring[slot * kVisTile + lane];
         const unsigned long long mask = __ballot(idx >= 0);
-        if (mask != 0ull) {                                  // else: empty tile (sky)
+        if (mask != 0ull || MULTI) {                         // else: empty tile (sky)
           const uint2 m = *reinterpret_cast<const uint2*>(ring + slot * kVisTile + 64);   // the record's header
           const uint32_t m0 = __builtin_amdgcn_readfirstlane(m.x), m1 = __builtin_amdgcn_readfirstlane(m.y);
-          const int col = int((m0 & 0xFFFFu) * 8u) + (lane & 7), row = int((m0 >> 16) * 8u) + (lane >> 3);
-          // The tile's frame is wave-uniform: its camera and seed come by scalar load.  Every hit pixel of
-          // the tile becomes a level-0 record on the queue now, with all its lanes at work: the primary
-          // ray and its hit point are rebuilt exactly as the visibility pass measured them.
-          const int frame = int(m1);
-          const RenderParams& p = params_here();
-          const FrameRec fr = as_const(p.frames)[frame];
-          int slotpix = 0;
+          int k = 0, sample = -1;
           if constexpr (SLOTS) {
             // the tile's slot: every pixel black until its record finishes (the misses stay so)
-            const int k = __ffs(int(slot_free)) - 1;
+            k = __ffs(int(slot_free)) - 1;
             slot_free &= ~(1u << k);
-            slotpix = k * 64 + lane;
-            slot_stage[slotpix] = 0u;
-            slot_left |= (unsigned long long)__popcll(mask) << (8 * k);      // (the byte is 0: the slot was free)
-            if (lane == 0) { slot_hdr[2 * k] = m0; slot_hdr[2 * k + 1] = m1; }
-          }
-          if (idx >= 0) {
-            const rt_camera& cam = fr.cam;
-            const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
-            uint32_t pixel_key;
-            float dx, dy, dz, px, py, pz;
-            primary_ray<MODE>(p, cam, fr.seed, p.x0 + col, y, p.sample_index, pixel_key, dx, dy, dz);
-            if (CUBES && idx >= p.n_spheres) {
-              float t = 0.f;
-              int face = 0;
-              const int c = idx - p.n_spheres;
-              cube_t(sg[p.n_spheres + 2 * c], sg[p.n_spheres + 2 * c + 1], cam.origin[0], cam.origin[1], cam.origin[2],
-                     dx, dy, dz, frcp(dx), frcp(dy), frcp(dz), t, face);
-              hit_point<CUBES>(sg, p.n_spheres, idx, face, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t,
-                               px, py, pz);                                                                        // :168
+            if constexpr (MULTI) {
+              // (this is sample 0's record; its header also says which samples of the tile hit anything)
+              const uint2 sm = *reinterpret_cast<const uint2*>(ring + slot * kVisTile + 68);
+              // (readfirstlane returns a signed int: without the casts bit 31 would smear over the upper word)
+              unsigned long long todo = ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(sm.y)) << 32) |
+                                        (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(sm.x));
+              slot_sum[k * 192 + lane] = 0.f; slot_sum[k * 192 + 64 + lane] = 0.f; slot_sum[k * 192 + 128 + lane] = 0.f;
+              if (todo & 1ull) sample = 0;
+              todo &= ~1ull;
+              if (lane == 0) {
+                slot_hdr[kSlotHdr * k] = m0; slot_hdr[kSlotHdr * k + 1] = m1;
+                slot_hdr[kSlotHdr * k + 2] = uint32_t(todo); slot_hdr[kSlotHdr * k + 3] = uint32_t(todo >> 32);
+              }
+              if (todo != 0ull) request_next(k, m0, m1, __ffsll((long long)todo) - 1);
+              if (sample < 0) slot_ready |= 1u << k;           // nothing in sample 0: the next one can come in at once
             } else {
-              const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-              float dl;
-              const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
-              px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
+              slot_stage[k * 64 + lane] = 0u;
+              if (lane == 0) { slot_hdr[kSlotHdr * k] = m0; slot_hdr[kSlotHdr * k + 1] = m1; }
             }
-            const int e = n_bounce + lanes_below(mask);
-            q.at(0, e) = px; q.at(1, e) = py; q.at(2, e) = pz;
-            q.at(3, e) = dx; q.at(4, e) = dy; q.at(5, e) = dz;
-            q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
-            if constexpr (!REFR) { q.at(9, e) = 0.f; q.at(10, e) = 0.f; q.at(11, e) = 0.f; }   // acc = 0
-            if constexpr (SLOTS) {
-              q.at(kFMeta, e) = __uint_as_float(pack_meta_slot(0, slotpix, idx));
-            } else {
-              q.at(kFPixel, e) = __uint_as_float(uint32_t(row) * uint32_t(p.nx) + uint32_t(col));
-              q.at(kFMeta, e) = __uint_as_float(pack_meta(0, frame, idx));
-            }
-            q.at(kFKey, e) = __uint_as_float(pixel_key);
           }
-          n_bounce += __popcll(mask);
+          if (!MULTI || sample >= 0) take_in(idx, mask, m0, m1, sample, k);
         }
         if (n_bounce >= 64 || (SLOTS && slot_free == 0u)) consuming = false;   // one more turn: refill, then shade
       }
@@ -1915,7 +2025,13 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           }
         }
         if (!again) {
-          if constexpr (SLOTS) {
+          if constexpr (MULTI) {
+            // color = color + trace_ray(...) (:296): this sample joins the pixel's sum in its tile's slot (no other
+            // record of the pixel is in flight: a slot takes its samples in one after another)
+            const int sp = meta_slotpix(meta);
+            float* sum = slot_sum + (sp >> 6) * 192 + (sp & 63);
+            sum[0] += ar; sum[64] += ag; sum[128] += ab;
+          } else if constexpr (SLOTS) {
             // the pixel waits in its tile's slot; the tile leaves when its last pixel is in (below)
             slot_stage[meta_slotpix(meta)] = pack_rgbx(ar, ag, ab);
           } else {
@@ -1963,10 +2079,22 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void rt_stream_kernel(co
           do {
             const int k = __ffs(int(complete)) - 1;
             complete &= complete - 1u;
+            uint32_t rgbx;
+            if constexpr (MULTI) {
+              // a sample of the tile is finished: the next one comes in (top of the loop), or, after the last,
+              // the mean over samples is quantised (render_pixel :297, render :318, :325)
+              if ((__builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 2]) | __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 3])) != 0u) {
+                slot_ready |= 1u << k;
+                continue;
+              }
+              const float* sum = slot_sum + k * 192 + fl;
+              rgbx = pack_rgbx(sum[0] * p.inv_samples, sum[64] * p.inv_samples, sum[128] * p.inv_samples);
+            } else {
+              rgbx = slot_stage[k * 64 + fl];
+            }
             slot_free |= 1u << k;
-            const uint32_t rgbx = slot_stage[k * 64 + fl];
-            const uint32_t m0 = __builtin_amdgcn_readfirstlane(slot_hdr[2 * k]);
-            const uint32_t frame = __builtin_amdgcn_readfirstlane(slot_hdr[2 * k + 1]);
+            const uint32_t m0 = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k]);
+            const uint32_t frame = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 1]);
             const int col0 = int((m0 & 0xFFFFu) * 8u), row0 = int((m0 >> 16) * 8u);
             uint8_t* out = p.out_rgb + (long long)frame * p.frame_stride_px * 3;
             const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
@@ -2171,6 +2299,8 @@ struct rt_ctx {
   FrameRec* d_frames = nullptr;  // [kMaxBatch] cameras and seeds of the batch in flight
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
+  unsigned long long* d_present = nullptr;   // samples in one stream launch: per tile, the samples that hit (grown on demand)
+  size_t present_words = 0;
   int* d_chunk = nullptr;        // stream kernel's tile counters (kTileCounters, one per 128-byte line), followed
   size_t chunk_bytes = 0;        // by the occupancy words of the batch's tiles (grown on demand)
   size_t vis_elems = 0;
@@ -2208,8 +2338,8 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres, bool refr = false, bool slots = false) {
-  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, slots)) * (kBlock / 64);
+size_t stream_lds(int n_spheres, bool refr = false, int out = 0) {
+  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * (kBlock / 64);
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -2338,19 +2468,28 @@ void build_occluder_table(const float* geom4, int n, const DevLights& L, std::ve
 
 // kernel variants: RNG mode x refraction in the scene x cubes in the scene
 using RenderKernel = void (*)(const RenderParams);
-RenderKernel pick_visibility_kernel(int rng_mode, bool cubes) {
+RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false) {
+  if (multi) {
+    if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true, true> : rt_visibility_kernel<RT_RNG_KEYED, false, true>;
+    return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false, true>;
+  }
   if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true> : rt_visibility_kernel<RT_RNG_KEYED, false>;
   return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false>;
 }
-RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false, bool slots = false) {
-  if (slots && !refr) {   // finished pixels leave tile by tile (the default for 8-bit frames)
-    if (grid && !cubes)
-      return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true, true>
-                                      : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true, true>;
-    if (rng_mode == RT_RNG_KEYED)
-      return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, false, true> : rt_stream_kernel<RT_RNG_KEYED, false, false, false, true>;
-    return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, false, true> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, false, true>;
-  }
+template <int OUT>
+RenderKernel pick_slot_kernel(int rng_mode, bool cubes, bool grid) {
+  if (grid && !cubes)
+    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true, OUT>
+                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true, OUT>;
+  if (rng_mode == RT_RNG_KEYED)
+    return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, false, OUT> : rt_stream_kernel<RT_RNG_KEYED, false, false, false, OUT>;
+  return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, false, OUT> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, false, OUT>;
+}
+// out: 0 = finished pixels are stored one by one, 1 = tile by tile (the default for 8-bit frames), 2 = tile by
+// tile with all samples of a pixel in one launch
+RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false, int out = 0) {
+  if (out == 1 && !refr) return pick_slot_kernel<1>(rng_mode, cubes, grid);
+  if (out == 2 && !refr) return pick_slot_kernel<2>(rng_mode, cubes, grid);
   if (grid && !refr && !cubes)
     return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true>
                                     : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true>;
@@ -2406,11 +2545,13 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const bool cubes = ctx->n_cubes > 0;
   if ((refr || cubes) && ctx->kernel != RT_KERNEL_STREAM)
     return fail(ctx, RT_ESTATE, "refractive materials and cubes need the default kernel (RT_KERNEL_STREAM)");
-  if (ws && (samples > 1 || refr || n_frames != 1 || ctx->kernel != RT_KERNEL_STREAM))
+  if (ws && (samples != 1 || refr || n_frames != 1 || ctx->kernel != RT_KERNEL_STREAM))
     return fail(ctx, RT_EINVAL, "rt_render_noalloc renders one frame at one sample per pixel of a scene without refraction "
                                 "with the default kernel (samples %d, refractive %d): the other cases need buffers "
                                 "that are allocated on demand", samples, int(refr));
-  if (samples > 1 || refr) {  // running sums over samples (and tree nodes), one slab per frame of a batch
+  const bool stream_kernel_early = ctx->kernel == RT_KERNEL_STREAM;
+  const bool multi_early = stream_kernel_early && ctx->tile_flush && !refr && out_rgb && !out_f32 && samples >= 2 && samples <= 64;
+  if ((samples > 1 && !multi_early) || refr) {  // running sums over samples (and tree nodes), one slab per frame of a batch
     const size_t need = size_t(win_px) * 3 * size_t(batch);
     if (need > ctx->accum_floats) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2438,8 +2579,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   // 8-bit frames at one sample per pixel: the stream kernel stages finished pixels per tile and stores whole tiles
-  const bool slots = stream_kernel && ctx->tile_flush && !refr && samples == 1 && out_rgb && !out_f32;
-  const size_t vis_need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch);   // whole 8x8 tiles, odd pitch
+  // ... and with 2..64 samples per pixel all of them are traced in ONE launch pair and summed in the slots
+  const int slots = (stream_kernel && ctx->tile_flush && !refr && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
+  const bool multi = slots == 2;
+  const size_t vis_need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch) *
+                          size_t(multi ? samples : 1);   // whole 8x8 tiles, odd pitch; MULTI: a record per sample
   if (stream_kernel && !ws) {  // primary-hit indices handed from the visibility pass to the stream kernel
     const size_t need = vis_need;
     if (need > ctx->vis_elems) {
@@ -2483,6 +2627,17 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const long long batch_tiles = frame_tiles * batch;
   const int occ_words = int(((batch_tiles + kTileCounters - 1) / kTileCounters + 31) / 32) + 1;
   const size_t chunk_need = size_t(kTileCounters) * 128 + size_t(kTileCounters) * size_t(occ_words) * 4;
+  if (multi) {   // (never with `ws`: rt_render_noalloc takes one sample per pixel)
+    const size_t need = size_t(batch_tiles) + 8;   // (+8: a wave reads the words of its four tiles, also past the last id)
+    if (need > ctx->present_words) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_present) RT_HIP(ctx, hipFree(ctx->d_present));
+      ctx->d_present = nullptr; ctx->present_words = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_present, need * sizeof(unsigned long long)));
+      ctx->present_words = need;
+    }
+  }
+  p.present = ctx->d_present;
   if (stream_kernel && !ws) {
     const size_t need = chunk_need;
     if (need > ctx->chunk_bytes) {
@@ -2520,6 +2675,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.accum_stride_px = win_px;
   p.tile_pitch = p.tiles8_x | 1;
   p.vis_stride = (long long)p.tile_pitch * p.tiles8_y * kVisTile;
+  p.vis_sample_stride = p.vis_stride * batch;
   unsigned per_frame;
   if (stream_kernel) {
     p.strips_x = p.tiles8_x; p.strips_y = p.tiles8_y;   // work units of the stream kernel: 8x8 tiles
@@ -2558,13 +2714,15 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     }
     if (refr)   // every node of every sample adds into the pixel sums
       RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));
+    if (multi)   // which samples of a tile hit anything: collected by the visibility launches below
+      RT_HIP(ctx, hipMemsetAsync(ctx->d_present, 0, (size_t(frame_tiles) * size_t(nf) + 8) * sizeof(unsigned long long), ctx->stream));
     for (int s = 0; s < samples; ++s) {
       p.sample_index = s;
       if (stream_kernel) {
         // one wave per pair of 8x8 tiles, 8 tiles (64 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
         const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf));
         const size_t vlds = 0;
-        ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel
+        ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         // (and never more than the LDS lets stay resident)
         const unsigned per_cu = unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
@@ -2572,10 +2730,12 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
         // keeps the last call's contents)
-        RT_HIP(ctx, hipMemsetAsync(d_chunk, 0, chunk_need, ctx->stream));
-        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes), vgrid, dim3(kBlock), vlds, ctx->stream, p);
-        hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
-        if (refr && s + 1 == samples)
+        if (!multi || s == 0) RT_HIP(ctx, hipMemsetAsync(d_chunk, 0, chunk_need, ctx->stream));
+        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi), vgrid, dim3(kBlock), vlds, ctx->stream, p);
+        // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
+        if (!multi || s + 1 == samples)
+          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
+        if (refr && s + 1 == samples)   // (never MULTI)
           hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
                              ctx->stream, p);
       } else {
@@ -2666,11 +2826,13 @@ int rt_create(int device_id, rt_ctx** out) {
   for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
     if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, true), big)) != hipSuccess)
       return bail(e, "hipFuncSetAttribute");
-  const size_t bigs = stream_lds(RT_MAX_SPHERES, false, true);
-  for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-    for (int v = 0; v < 3; ++v)   // plain, cubes, grid
-      if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2, true), bigs)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute");
+  for (int out = 1; out <= 2; ++out) {
+    const size_t bigs = stream_lds(RT_MAX_SPHERES, false, out);
+    for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
+      for (int v = 0; v < 3; ++v)   // plain, cubes, grid
+        if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2, out), bigs)) != hipSuccess)
+          return bail(e, "hipFuncSetAttribute");
+  }
   if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
       (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
@@ -2697,6 +2859,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   if (ctx->d_spill) (void)hipFree(ctx->d_spill);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);
+  if (ctx->d_present) (void)hipFree(ctx->d_present);
   if (ctx->d_chunk) (void)hipFree(ctx->d_chunk);
   delete ctx;
 }

@@ -339,6 +339,40 @@ def test_tile_flush_changes_no_byte(renderer):
         renderer.set_tile_flush(True)
 
 
+def test_samples_in_one_launch_change_no_byte(renderer):
+    """2..64 samples per pixel are traced in ONE launch pair, each tile slot summing its samples in LDS in sample
+    order (render_pixel :292-297); with RT_OPT_TILE_FLUSH off — and beyond 64 samples — every sample is a launch pair
+    of its own that adds into a float frame in memory.  Same sums, same bytes, same ray counts: ragged sizes, deep
+    bounces, cubes, sparse tiles (samples of a tile that hit nothing: no record), both RNG modes, frame batches."""
+    import torch
+    from raytracer_amd.scenes import cube_scene
+    cases = [(generate_scene(8, 1, keep_default=True), 960, 540, 5, (2, 4)), (generate_scene(64, 2), 640, 360, 8, (3,)),
+             (default_scene(), 333, 187, 5, (2, 7)), (generate_scene(300, 7), 320, 180, 5, (2,)),
+             (cube_scene(), 320, 179, 5, (2,)), (default_scene(), 64, 48, 3, (64, 65)), (default_scene(), 5, 3, 5, (2,))]
+    try:
+        for scene, w, h, D, spps in cases:
+            for spp in spps:
+                out = []
+                for on in (True, False):
+                    renderer.set_tile_flush(on)
+                    renderer.upload_scene(scene)
+                    renderer.reset_ray_counts()
+                    frames = [renderer.render(w, h, spp, max_depth=D, rng_mode=mode, seed=9, camera=cam, return_hit_index=True)
+                              for cam, mode in ((None, "K"), (orbit_camera(37, 256), "K"), (None, "C"))]
+                    rows = renderer.render_rows(w, h, spp, tile_rows=5, tile_first=1, tile_stride=3, max_depth=D, seed=2)
+                    F = 3
+                    slab = torch.full((F, h + 2, w, 3), 7, dtype=torch.uint8, device="cuda:0")
+                    renderer.render_frames([orbit_camera(f, 64) for f in range(F)], list(range(F)), w, h, spp, max_depth=D, out=slab)
+                    out.append((frames, rows, slab, renderer.ray_counts()))
+                (fa, ra, sa, ca), (fb, rb, sb, cb) = out
+                for (a, ha), (b, hb) in zip(fa, fb):
+                    assert torch.equal(a, b) and torch.equal(ha, hb), (w, h, spp)
+                assert torch.equal(ra, rb) and torch.equal(sa, sb) and ca == cb, (w, h, spp)
+                assert int(sa[:, h:].min()) == 7 and int(sa[:, h:].max()) == 7
+    finally:
+        renderer.set_tile_flush(True)
+
+
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
     pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""

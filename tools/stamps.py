@@ -9,6 +9,7 @@ from raytracer_amd.scenes import Camera
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "t64"
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+SPP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
 r = Renderer(0)
 r.upload_scene(bench.build_scene(wl))
@@ -16,7 +17,7 @@ if os.environ.get("RT_BENCH_NO_TILE_FLUSH"):
     r.set_tile_flush(False)
 for it in range(2):
     r.reset_ray_counts()
-    r.render_frames([Camera()] * F, range(F), w, h, 1, max_depth=D)
+    r.render_frames([Camera()] * F, range(F), w, h, SPP, max_depth=D)
 a = (ctypes.c_uint64 * 16)()
 r._check(r._L.rt_debug_counters(r._h, a))
 # word 8 holds a per-slot atomicMax of the wave lifetime; rt_debug_counters sums the 64 slots, so it
