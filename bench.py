@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """rt355 benchmark: Mrays/s (primary + reflection + shadow) at 1080p, depth 5.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|t64|c3|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|t64|c3|c1|c4|c5|refr|cubes|cubes_glass]
 
 One "step" = one batch of ``--frames`` (default 1024, = one kernel launch pair) 1080p frames of BASELINE.json config 2
 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per shaded hit, keyed RNG, seed = frame
 index), inputs (scene) already resident on the GPU.  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
 (tile t -> rank t mod N), each rank renders its tiles of all frames of the batch, and ONE RCCL
-gather per step moves the packed tiles (only their non-black 32-byte segments: lossless, see
-raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_scatter_rows puts them in image order:
-total work per step is fixed => "strong" scaling.  Rays are counted by the kernel itself
-(rt_get_ray_counts), not modelled.
+gather per step moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
+raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_place_tiles writes the frames in image order:
+total work per step is fixed => "strong" scaling.  ``--workload c5`` at N > 1 is BASELINE config 5's mode
+instead: frame f -> rank f mod N, whole frames, no exchange inside the timed region; the one gather at the end
+is timed separately (``final_gather_ms``).  Rays are counted by the kernels themselves (rt_get_ray_counts), not
+modelled.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — FP32-VALU roofline of the launch pair rt_visibility_kernel + rt_stream_kernel (one
-                 pair per batch and sample: primary rays / everything after them) from algorithmic
-                 flops and the pair's live HIP-event duration on its launch stream;
+                 pair per batch: primary rays / everything after them).  `achieved` / `frac` are the ALGORITHMIC
+                 flops of the reference's brute-force algorithm over the pair's live HIP-event
+                 duration: a speed-of-algorithm figure, not VALU utilisation (the kernels cull most of that work).
+                 `executed_frac` (FP32 flops the VALUs executed / peak) and `issue_frac` (vector + scalar
+                 wave-instructions / issue slots) say what the hardware did: per-ray PMC counts from the committed
+                 rocprofv3 pass named in `pmc_profile`, scaled by this run's rays and divided by this run's time;
+  target_64sph — the same measurement, shorter, on the north-star target scene (1080p, depth 5, 64 spheres);
   cpu_baseline — the FP64 C++ restatement of the reference (oracle/, "port") timed on this
                  host's cores on a bounded number of whole frames of the same workload (rank 0, N = 1 only).
 """
@@ -32,8 +39,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
-MEASURED_TRAFFIC_C2 = 3.26e10       # bytes per 1024-frame launch pair, profiles/r1m_c2_* (see roofline.traffic)
+ISSUE_SLOTS_PER_S = 256 * 4 * 2.4e9 / 2   # a SIMD-32 issues one wave64 vector instruction per 2 clocks
 PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 core (cannot run here)
+
+# Per-launch-pair PMC sums of the committed rocprofv3 passes (tools/profile.sh + tools/summarize_profile.py), both
+# kernels of a 1024-frame, 1-spp launch pair: FP32 flops the VALUs executed (SQ_INSTS_VALU_{ADD,MUL,TRANS}_F32 +
+# 2 x FMA, x 64 lanes: a full-wave upper bound), vector and scalar wave-instructions, HBM bytes
+# (TCC_EA0_WRREQ x 64 + TCC_EA0_RDREQ x 64 x 2, the guide's gfx950 correction), and the rays of that launch pair.
+# (tools/pmc_constants.py prints these lines from a tools/profile.sh directory.)
+PMC = {
+}
 
 WORKLOADS = {
     # name: (width, height, n_spheres, scene seed, keep_default, max_depth, description)
@@ -65,10 +80,9 @@ def build_scene(wl):
     return default_scene() if n == 3 else generate_scene(n, sseed, w, h, keep_default=keep)
 
 
-def cpu_baseline(wl, target_s=15.0):
+def cpu_baseline(wl, target_s=5.0):
     """Time the oracle (FP64 restatement of the reference) on this host, all cores, on whole frames
     of the same workload until ~target_s seconds of CPU time have been spent."""
-    import numpy as np
     from oracle import cpu_oracle
     w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
     scene = build_scene(wl)
@@ -110,7 +124,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--kernel", default="stream", choices=["stream", "pixel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-target", action="store_true", help="skip the second timed region on the 64-sphere target scene")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0)
     args = ap.parse_args()
 
     import torch
@@ -138,145 +153,211 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    from raytracer_amd.distributed import BatchExchange
-    from raytracer_amd.render import Renderer
-    from raytracer_amd.scenes import pack_scene
     from raytracer_amd import tiling
+    from raytracer_amd._lib import FRAMES_PER_LAUNCH
+    from raytracer_amd.distributed import BatchExchange, frames_of_rank, gather_frames
+    from raytracer_amd.render import Renderer
+    from raytracer_amd.scenes import Camera, orbit_camera, pack_scene
 
-    w, h, n_sph, _, _, D, desc = WORKLOADS[args.workload]
-    F, tr = args.frames, args.tile_rows
-    scene = build_scene(args.workload)
-    packed = pack_scene(scene)
+    dev = f"cuda:{local_rank}"
+    red_dev = "cpu" if backend == "gloo" else dev
     r = Renderer(local_rank)
-    r.upload_scene(packed)
     r.set_kernel(args.kernel)
     if os.environ.get("RT_BENCH_NO_SPILL"):     # A/B of the refractive queue's spill stack
         r.set_queue_spill(False)
     if os.environ.get("RT_BENCH_NO_TILE_FLUSH"):  # A/B of the stream kernel's coalesced output path
         r.set_tile_flush(False)
+    buffers = {}                                # frame / exchange buffers, reused by workloads of the same size
 
-    rows_max = tiling.max_local_rows(h, tr, world)
-    slab_bytes = rows_max * w * 3
-    dev = f"cuda:{local_rank}"
-    if rank == 0:
-        frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device=dev)
-    # N > 1: every rank renders its row tiles of the F frames of a step into a slab; one gather per step
-    # moves the slabs to GPU 0, where one launch puts the rows in image order.  Double-buffered: the
-    # gather of step i (RCCL's stream) overlaps the render of step i + 1.
-    # Only the 32-byte segments of a slab that are not black travel (lossless, BatchExchange(sparse=True)): the
-    # exchange, not the rays, bounds N > 1.  RT_BENCH_DENSE=1 sends whole slabs.
-    # The root puts gathered segments straight into image order (segments_to_frames: no dense gather buffer).
-    from raytracer_amd.distributed import segments_to_frames
-    direct = (w * 3) % 32 == 0 and not os.environ.get("RT_BENCH_DENSE_PLACE")
-    ex = BatchExchange(F, slab_bytes, dev,
-                       lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out),
-                       sparse=not os.environ.get("RT_BENCH_DENSE"),
-                       place_segments=(lambda rows, counts, i: segments_to_frames(rows, counts, frames_out, w, h, tr, rows_max))
-                       if direct else None) \
-        if (world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE")) else None   # (env: rehearse this path on 1 GPU)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    def measure(wl, F, steps, warmup, samples):
+        """warmup + `steps` timed steps of workload `wl`; returns the numbers of the JSON line (rank 0) or None."""
+        w, h, n_sph, _, _, D, desc = WORKLOADS[wl]
+        tr = args.tile_rows
+        packed = pack_scene(build_scene(wl))
+        r.upload_scene(packed)
+        frame_parallel = wl == "c5" and world > 1           # BASELINE config 5: frame f -> rank f mod N, whole frames
+        rows_max = h if frame_parallel else tiling.max_local_rows(h, tr, world)
+        slab_bytes = rows_max * w * 3
+        key = (w, h, F, frame_parallel)
+        if buffers.get("key") != key:
+            buffers.clear()
+            buffers["key"] = key
+            if rank == 0 or frame_parallel:
+                n_local = len(frames_of_rank(F, rank, world)) if frame_parallel else F
+                buffers["frames_out"] = torch.empty((n_local, h, w, 3), dtype=torch.uint8, device=dev)
+            # N > 1: every rank renders its row tiles of the F frames of a step into a slab; one gather per step
+            # moves the occupied tiles of the slabs to GPU 0, where one pass writes the frames in image order.
+            # Pipelined: compaction, gather and placement of earlier steps overlap the render of later ones, and no
+            # rank's host waits for its own render (BatchExchange).  RT_BENCH_DENSE=1 sends whole slabs.
+            use_ex = (world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE")) and not frame_parallel   # (env: rehearse on 1 GPU)
+            if use_ex:
+                fo = buffers.get("frames_out")
+                if os.environ.get("RT_BENCH_DENSE"):
+                    buffers["ex"] = BatchExchange(F, slab_bytes, dev,
+                                                  lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=fo))
+                else:
+                    table = {}
 
-    from raytracer_amd.scenes import Camera
-    cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
-    if args.workload == "c5":                   # BASELINE config 5: frame f of a 256-frame orbit
-        from raytracer_amd.scenes import orbit_camera
-        cams = [orbit_camera(f % 256, 256) for f in range(F)]
-    cams = r.pack_cameras(cams)                 # packed once: the step loop must not be host-bound at N = 8
+                    def place_tiles(entries, counts, i):
+                        table["t"] = r.place_tiles(entries, counts, w, h, tr, fo, table.get("t"))
+                    buffers["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
+                                                  capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8))
+        ex = buffers.get("ex")
+        frames_out = buffers.get("frames_out")
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
-    def step(i, timed_idx=None):
-        # N = 1: the rank owns every row, so its packed slab IS the frame batch
-        out = frames_out if ex is None else ex.slab(i).view(F, rows_max, w, 3)
-        if timed_idx is not None:
-            ev[timed_idx][0].record()
-        r.render_frames(cams, range(i * F, (i + 1) * F), w, h, args.samples, max_depth=D, rng_mode="K",
-                        out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
-        if timed_idx is not None:
-            ev[timed_idx][1].record()
+        cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
+        if wl == "c5":                              # BASELINE config 5: frame f of a 256-frame orbit
+            cams = [orbit_camera(f % 256, 256) for f in range(F)]
+        mine = frames_of_rank(F, rank, world) if frame_parallel else None
+        if frame_parallel:
+            cams = [cams[int(f)] for f in mine]
+        cams = r.pack_cameras(cams)                 # packed once: the step loop must not be host-bound at N = 8
+
+        def step(i, timed_idx=None):
+            if timed_idx is not None:
+                ev[timed_idx][0].record()
+            if frame_parallel:                      # this rank's frames of the batch, whole
+                r.render_frames(cams, [i * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=frames_out)
+            else:
+                # N = 1: the rank owns every row, so its packed slab IS the frame batch
+                out = frames_out if ex is None else ex.slab(i).view(F, rows_max, w, 3)
+                r.render_frames(cams, range(i * F, (i + 1) * F), w, h, samples, max_depth=D, rng_mode="K",
+                                out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
+            if timed_idx is not None:
+                ev[timed_idx][1].record()
+            if ex is not None:
+                ex.submit(i)
+
+        def barrier():
+            if ex is not None:
+                ex.drain()         # the last steps' gathers and placements belong to the timed region
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for i in range(warmup):
+            step(i)
+        barrier()
+        r.reset_ray_counts()
         if ex is not None:
-            ex.submit(i)
+            ex.sent_bytes = 0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i, i)
+        barrier()
+        dt = time.perf_counter() - t0
 
-    def barrier():
-        if ex is not None:
-            ex.drain()         # the last steps' gathers and placements belong to the timed region
+        gather_ms = None
+        if frame_parallel:                          # config 5: the one exchange, after the clock has stopped
+            t1 = time.perf_counter()
+            gather_frames(frames_out, F)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - t1) * 1e3
+
+        rc = r.ray_counts()
+        stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=red_dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        # (refractive scenes: as many frames per launch pair as fit 32 GiB of float pixel sums, kRefrSumBytes in csrc/rt355.hip)
+        per_launch = min(FRAMES_PER_LAUNCH, max(1, (32 << 30) // (12 * rows_max * w))) if packed.has_refraction else FRAMES_PER_LAUNCH
+        n_local_frames = len(mine) if frame_parallel else F
+        one_stream_launch = samples == 1 or (2 <= samples <= 64 and not packed.has_refraction and args.kernel == "stream"
+                                             and not os.environ.get("RT_BENCH_NO_TILE_FLUSH"))
+        launches_per_step = -(-n_local_frames // per_launch) * (1 if one_stream_launch else samples)
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (steps * launches_per_step)
+        kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    r.reset_ray_counts()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, i)
-    barrier()
-    dt = time.perf_counter() - t0
-
-    rc = r.ray_counts()
-    red_dev = "cpu" if backend == "gloo" else dev
-    stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=red_dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    from raytracer_amd._lib import FRAMES_PER_LAUNCH
-    # (refractive scenes: as many frames per launch pair as fit 32 GiB of float pixel sums, kRefrSumBytes in csrc/rt355.hip)
-    per_launch = min(FRAMES_PER_LAUNCH, max(1, (32 << 30) // (12 * rows_max * w))) if packed.has_refraction else FRAMES_PER_LAUNCH
-    launches_per_step = -(-F // per_launch) * args.samples
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
-    kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-    total_rays, shaded, primary = (float(x) for x in stats.tolist())
-    dt = float(tmax.item())
-
-    if rank == 0:
-        # per-launch (per rank) algorithmic flops of rt_render_kernel on rank 0
-        launches = args.steps * launches_per_step
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        if rank != 0:
+            return None
+        total_rays, shaded, primary = (float(x) for x in stats.tolist())
+        dt = float(tmax.item())
+        launches = steps * launches_per_step
+        # per-launch (per rank) algorithmic flops of the launch pair on rank 0
         fl = algorithmic_flops(rc["total"], rc["shaded_hits"], n_sph, packed.area_samples) / launches
         achieved = fl / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "frac_is": "ALGORITHMIC: flops of the reference's brute-force algorithm (rays*(5+17N) + shaded*(55+75*(1+ns)), "
+                           "SURVEY.md 8d) per second / FP32 VALU peak - a speed-of-algorithm figure that exceeds 1 on many-sphere "
+                           "scenes because the kernels cull most of that work; VALU utilisation is executed_frac / issue_frac",
+                "traffic": None, "executed_frac": None, "issue_frac": None, "pmc_profile": None,
+                "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events also cover the ~4 us "
+                           "rt_camera_table_kernel, up to 16 frame-record stores and a 4 MB memset)")
+                if args.kernel == "stream" else "rt_pixel_kernel",
+                "kernel_ms": kern_ms, "flops_per_launch": fl}
+        pmc = PMC.get(wl)
+        if pmc and samples == 1 and args.kernel == "stream" and not os.environ.get("RT_BENCH_NO_TILE_FLUSH"):
+            # what the hardware executed: the profiled launch pair's counts per ray x this run's rays per launch
+            scale = (rc["total"] / launches) / pmc["rays"]
+            secs = kern_ms * 1e-3
+            roof["executed_frac"] = pmc["flops"] * scale / secs / 1e12 / PEAK_FP32_TFLOPS
+            roof["issue_frac"] = (pmc["valu"] + pmc["salu"]) * scale / secs / ISSUE_SLOTS_PER_S
+            roof["valu_issue_frac"] = pmc["valu"] * scale / secs / ISSUE_SLOTS_PER_S
+            roof["traffic"] = pmc["hbm_bytes"] * scale
+            roof["pmc_profile"] = pmc["profile"]
+            roof["pmc_note"] = ("executed_frac = FP32 flops the VALUs executed (PMC SQ_INSTS_VALU_*_F32, full-wave upper bound) / s / "
+                                "157.3 TFLOP/s; issue_frac = (vector + scalar wave-instructions) / (1024 SIMDs x 1.2e9 issue "
+                                "slots/s: one wave64 instruction per 2 clocks); traffic = HBM bytes per launch pair (TCC_EA0_*); "
+                                "PMC counts per ray from the named profile of this workload, scaled by this run's rays")
+        if frame_parallel:
+            par = f"frame-parallel x{world}: frame f -> rank f mod {world}, whole frames, one gather after the timed region"
+        elif world > 1:
+            par = f"row-tiles x{world} (tile {tr} rows) + RCCL gather to GPU 0" + \
+                  (" of the occupied 8x8 tiles" if ex is not None and ex.sparse else "")
+        else:
+            par = "single GPU"
+        out = {
+            "value": total_rays / dt / 1e6,
+            "ms_per_step": dt / steps * 1e3,
+            "config": {"workload": f"{desc}; batch of {F} frames per step, {samples} spp, "
+                                   f"keyed RNG, {n_sph} spheres, 12 area-light samples",
+                       "width": w, "height": h, "max_depth": D, "frames_per_step": F, "parallelism": par},
+            "rays_per_frame": total_rays / (steps * F),
+            "rays_per_pixel": total_rays / max(primary, 1.0),
+            "mpixels_per_s": primary / dt / 1e6,
+            "frames_per_s": steps * F / dt,
+            "exchange_bytes_per_step_rank0": (ex.sent_bytes / steps) if ex is not None else 0,
+            "roofline": roof,
+        }
+        if gather_ms is not None:
+            out["final_gather_ms"] = gather_ms
+            out["final_gather_note"] = (f"one gather of the last step's {F} frames to GPU 0 after the timed region; "
+                                        "frames_per_s is at render completion (SURVEY.md 8e)")
+        return out
+
+    res = measure(args.workload, args.frames, args.steps, args.warmup, args.samples)
+    target = None
+    if not args.no_target and args.workload != "t64":
+        # the north-star target scene (1080p, depth 5, 64 spheres), same frames per step, a shorter region
+        target = measure("t64", args.frames, max(2, min(args.steps, 6)), 1, 1)
+
+    if rank == 0:
         out = {
             "metric": "Mrays/s (primary+secondary) at 1080p depth 5",
-            "value": total_rays / dt / 1e6,
+            "value": res["value"],
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{desc}; batch of {F} frames per step, {args.samples} spp, "
-                                   f"keyed RNG, {n_sph} spheres, 12 area-light samples",
-                       "width": w, "height": h, "max_depth": D, "frames_per_step": F,
-                       "parallelism": f"row-tiles x{world} (tile {tr} rows) + RCCL gather to GPU 0"
-                                      + (" of the non-black 32-byte segments" if ex is not None and ex.sparse else "")
-                       if world > 1 else "single GPU"},
-            "rays_per_frame": total_rays / (args.steps * F),
-            "rays_per_pixel": total_rays / max(primary, 1.0),
-            "mpixels_per_s": primary / dt / 1e6,
-            "frames_per_s": args.steps * F / dt,
-            "exchange_bytes_per_step_rank0": (ex.sent_bytes / (args.steps + args.warmup)) if ex is not None else 0,
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         # HBM bytes per launch pair: a separate rocprofv3 --pmc pass of this same command
-                         # (tools/profile.sh; TCC_EA0_WRREQ_sum x 64 B + TCC_EA0_RDREQ_sum x 64 B x 2, the
-                         # gfx950 correction of MI355X_MICROARCH.md), profiles/r1m_c2_*: visibility 7.7e9 W,
-                         # stream 2.37e10 W + 1.1e9 R.  Known for the default workload only.
-                         "traffic": MEASURED_TRAFFIC_C2 if (args.workload == "c2" and F == 1024 and args.samples == 1
-                                                            and world == 1 and args.kernel == "stream") else None,
-                         "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events "
-                                    "also cover the ~4 us rt_camera_table_kernel, up to 16 frame-record stores and a 4 MB memset)")
-                         if args.kernel == "stream" else "rt_pixel_kernel", "kernel_ms": kern_ms,
-                         "flops_per_launch": fl,
-                         "note": "algorithmic flops = rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md 8d, i.e. "
-                                 "the brute-force count of the reference's algorithm: the kernels cull spheres (per object, per "
-                                 "shading point, per ray bundle) and execute ~3x fewer flops, so frac exceeds 1 on "
-                                 "many-sphere scenes (DESIGN.md 4, roofline); HBM traffic (PMC, profiles/r1m_*) is "
-                                 "~3.3e10 B per 1024-frame config-2 launch: the framebuffer, 2.25 B/pixel of hit indices and the "
-                                 "scattered pixel stores"},
         }
+        out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
+        if target is not None:
+            tr_ = target["roofline"]
+            out["target_64sph"] = {"value": target["value"], "unit": "Mrays/s", "ms_per_step": target["ms_per_step"],
+                                   "workload": target["config"]["workload"], "kernel_ms": tr_["kernel_ms"],
+                                   "algorithmic_frac": tr_["frac"], "executed_frac": tr_["executed_frac"],
+                                   "issue_frac": tr_["issue_frac"], "pmc_profile": tr_["pmc_profile"],
+                                   "frames_per_s": target["frames_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
         print(json.dumps(out), flush=True)

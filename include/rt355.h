@@ -226,6 +226,29 @@ int rt_scatter_rows_frames(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_st
                            int64_t frame_stride_bytes, int n_ranks, int n_frames, int width, int height,
                            int tile_rows, uint8_t* out_rgb);
 
+/* Multi-GPU exchange without black pixels (no reference counterpart: the reference has no distributed code; its
+ * unused render_chunk tile split, raytracer.py:299-308, is the model).  Most of a frame is background (81 % of
+ * config 2's 8x8 tiles), the renderer knows which tiles are not (the visibility pass's occupancy bits), and a rank
+ * renders several times what an xGMI link carries, so only occupied tiles travel.
+ *
+ * rt_compact_tiles (every rank, right after the render call that wrote `slab`, same stream): the occupied 8x8
+ *   tiles of that batch are copied into `entries` (device; capacity_tiles entries of RT_TILE_ENTRY_BYTES: uint32
+ *   tile id, then 8 rows x 24 bytes of packed RGB) and *count_dev (device uint32) receives their number, which may
+ *   exceed capacity_tiles (then entries were dropped: size the buffer for every tile, ((w+7)/8|1) * ((rows+7)/8)
+ *   per frame).  Tile id = (frame * tiles_y + tile_row) * pitch + tile_col, pitch = ((w+7)/8)|1, in the slab's own
+ *   row numbering.  `slab` must be the out_rgb of the last render call on this context (RT_ESTATE otherwise).
+ *   Nothing is read back: the host never waits for the render.
+ * rt_place_tiles (root, after the gather): entries [n_ranks][capacity_tiles] as gathered (rank r's written by
+ *   rt_render_frames_rows(tile_first = r, tile_stride = n_ranks) + rt_compact_tiles), counts_dev [n_ranks]
+ *   (device) -> out_rgb [n_frames][height][width][3], every byte written once: black where no entry covers it.
+ *   `table` is work space: table_words >= n_ranks * n_frames * (((width+7)/8)|1) * ((rows_max+7)/8) uint32,
+ *   rows_max = the rows of rank 0. */
+#define RT_TILE_ENTRY_BYTES 196
+int rt_compact_tiles(rt_ctx* ctx, const uint8_t* slab, uint8_t* entries, uint32_t* count_dev, int capacity_tiles);
+int rt_place_tiles(rt_ctx* ctx, const uint8_t* entries, const uint32_t* counts_dev, int n_ranks, int capacity_tiles,
+                   int n_frames, int width, int height, int tile_rows, uint32_t* table, int64_t table_words,
+                   uint8_t* out_rgb);
+
 /* Ray statistics accumulated by every render call since the last reset (device counters; this
  * call synchronises the stream).  out[0] = primary rays, out[1] = reflection rays,
  * out[2] = shadow rays, out[3] = shaded hits (compute_lighting calls).  A "ray" is one

@@ -2235,6 +2235,136 @@ __global__ __launch_bounds__(256) void rt_scatter_rows_kernel(const uint8_t* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-GPU exchange: only the tiles of a rank's slab that hold something travel.
+//
+// Sender (rt_compact_tiles): the visibility pass has already marked the 8x8 tiles of the batch in which some
+// pixel hit something (`occ`, one bit per tile id); every other tile is black.  One lane looks at one tile id;
+// a wave reserves room for its occupied tiles with one atomic and copies each as an entry
+//     { uint32 tile id, 8 rows x 24 bytes of packed RGB }  = kTileEntryBytes
+// (48 lanes x one dword where rows are dword-aligned).  The number of entries stays on the device: no rank's
+// host waits for its render.  SCAN: no occupancy bits at hand (the batch took several launches, or samples were
+// separate launches): a tile is kept if some byte of it is not zero.
+// ------------------------------------------------------------------------------------------
+constexpr int kTileEntryBytes = RT_TILE_ENTRY_BYTES;
+static_assert(kTileEntryBytes == 4 + 8 * 24, "entry = tile id + 8 rows of 8 RGB pixels");
+struct TileGeom {          // the slab of one rank: n_frames windows of n_rows x nx pixels, frame_stride_px apart
+  int nx, n_rows, n_frames, tiles8_x, tiles8_y, tile_pitch;
+  long long frame_stride_px;
+};
+template <bool SCAN>
+__global__ __launch_bounds__(256) void rt_compact_tiles_kernel(const uint8_t* __restrict__ slab, TileGeom g,
+                                                               const uint32_t* __restrict__ occ, int occ_words,
+                                                               uint8_t* __restrict__ entries, unsigned int* __restrict__ count,
+                                                               unsigned int capacity) {
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)g.tile_pitch * g.tiles8_y * g.n_frames;
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_frame = g.tile_pitch * g.tiles8_y;
+  bool keep = false;
+  int frame = 0, ty = 0, tx = 0;
+  if (id < total) {
+    frame = int(id / per_frame);
+    const int rem = int(id - (long long)frame * per_frame);
+    ty = rem / g.tile_pitch; tx = rem - ty * g.tile_pitch;
+    if (tx < g.tiles8_x) {                                   // (the odd pitch leaves padding ids without a tile)
+      if constexpr (SCAN) {
+        const int rows = min(8, g.n_rows - ty * 8), nbytes = min(8, g.nx - tx * 8) * 3;
+        const uint8_t* src = slab + ((long long)frame * g.frame_stride_px + (long long)(ty * 8) * g.nx + tx * 8) * 3;
+        unsigned int any = 0u;
+        for (int r = 0; r < rows; ++r)
+          for (int b = 0; b < nbytes; ++b) any |= src[(long long)r * g.nx * 3 + b];
+        keep = any != 0u;
+      } else {
+        const uint32_t slot = uint32_t(id) / kTileCounters, h = uint32_t(id) % kTileCounters;
+        keep = (occ[size_t(h) * size_t(occ_words) + (slot >> 5)] >> (slot & 31u)) & 1u;
+      }
+    }
+  }
+  const unsigned long long kept = __ballot(keep);
+  if (kept == 0ull) return;
+  unsigned int base = 0u;
+  if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(kept));
+  base = __builtin_amdgcn_readfirstlane(base);
+  const bool dwords = (g.nx & 3) == 0 && (g.frame_stride_px & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 3) == 0;
+  unsigned long long todo = kept;
+  int k = 0;
+  while (todo != 0ull) {                                     // the wave copies its kept tiles one after another
+    const int src_lane = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const unsigned int slot = base + unsigned(k++);
+    if (slot >= capacity) continue;                          // (the count still says how many there were: the host checks)
+    const int f = __builtin_amdgcn_readlane(frame, src_lane), y0 = __builtin_amdgcn_readlane(ty, src_lane) * 8,
+              x0 = __builtin_amdgcn_readlane(tx, src_lane) * 8;
+    const unsigned int tid = unsigned(__builtin_amdgcn_readlane(int(uint32_t(id)), src_lane));
+    uint8_t* e = entries + size_t(slot) * kTileEntryBytes;
+    if (lane == 0) *reinterpret_cast<uint32_t*>(e) = tid;
+    const uint8_t* src = slab + ((long long)f * g.frame_stride_px + (long long)y0 * g.nx + x0) * 3;
+    const int rows = min(8, g.n_rows - y0), cols = min(8, g.nx - x0);
+    if (dwords && cols == 8) {
+      const int r = (lane * 43) >> 8, w = lane - 6 * r;     // lane l < 48: dword w of tile row r
+      if (lane < 48)
+        reinterpret_cast<uint32_t*>(e + 4)[lane] =
+            r < rows ? *reinterpret_cast<const uint32_t*>(src + (long long)r * g.nx * 3 + w * 4) : 0u;
+    } else {
+      for (int b = lane; b < 192; b += 64) {
+        const int r = b / 24, c = b - 24 * r;
+        e[4 + b] = (r < rows && c < cols * 3) ? src[(long long)r * g.nx * 3 + c] : uint8_t(0);
+      }
+    }
+  }
+}
+
+// Root, step 1: where is the entry of a tile?  table[rank][tile id] = entry number + 1 (0 = none: the tile is black)
+__global__ __launch_bounds__(256) void rt_index_tiles_kernel(const uint8_t* __restrict__ entries, const unsigned int* __restrict__ counts,
+                                                             int capacity, long long ids_per_rank, uint32_t* __restrict__ table) {
+  const int rank = blockIdx.y;
+  const unsigned int n = min(counts[rank], (unsigned int)capacity);
+  for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint32_t id = *reinterpret_cast<const uint32_t*>(entries + (size_t(rank) * capacity + k) * kTileEntryBytes);
+    if ((long long)id < ids_per_rank) table[(long long)rank * ids_per_rank + id] = k + 1u;
+  }
+}
+
+// Root, step 2: every row of every frame, written once — black where no entry covers it.  Image row y belongs to
+// row tile t = y / tile_rows of rank t mod n_ranks and is that rank's local row (t / n_ranks) tile_rows + y mod
+// tile_rows (rt_render_rows); the 24 bytes of an 8-pixel segment come from row (local row mod 8) of the entry of
+// the rank's tile (local row / 8, x / 8).  A workgroup writes a band of 8 image rows of one frame, a thread one
+// dword of a row at a time (bytes when rows are not dword-aligned): consecutive lanes, consecutive addresses.
+__global__ __launch_bounds__(256) void rt_place_tiles_kernel(const uint8_t* __restrict__ entries, const uint32_t* __restrict__ table,
+                                                             int capacity, long long ids_per_rank, int n_ranks, int width, int height,
+                                                             int tile_rows, uint8_t* __restrict__ out, int vec4) {
+  const int frame = blockIdx.y;
+  const int tiles8_x = (width + 7) / 8, pitch = tiles8_x | 1;
+  const int n_tiles = (height + tile_rows - 1) / tile_rows;
+  const int row_bytes = width * 3;
+  for (int y = int(blockIdx.x) * 8; y < min(height, int(blockIdx.x) * 8 + 8); ++y) {
+    const int t = y / tile_rows, rank = t % n_ranks;
+    const int lr = (t / n_ranks) * tile_rows + (y - t * tile_rows);
+    // rows of this rank's window (its tile ids count ITS tile rows): row tiles rank, rank + n_ranks, ... of the frame
+    const int mine = n_tiles > rank ? (n_tiles - rank + n_ranks - 1) / n_ranks : 0;
+    const int rows_r = mine * tile_rows - (((n_tiles - 1) % n_ranks == rank) ? n_tiles * tile_rows - height : 0);
+    const int tiles8_y = (rows_r + 7) / 8;
+    const uint32_t* trow = table + (long long)rank * ids_per_rank + (long long)frame * pitch * tiles8_y + (long long)(lr >> 3) * pitch;
+    const uint8_t* erow = entries + size_t(rank) * capacity * kTileEntryBytes + 4 + (lr & 7) * 24;
+    uint8_t* dst = out + ((long long)frame * height + y) * row_bytes;
+    if (vec4) {
+      for (int w = threadIdx.x; w < row_bytes / 4; w += 256) {
+        const int tx = w / 6, dw = w - 6 * tx;
+        const uint32_t slot = trow[tx];
+        reinterpret_cast<uint32_t*>(dst)[w] =
+            slot ? *reinterpret_cast<const uint32_t*>(erow + size_t(slot - 1u) * kTileEntryBytes + dw * 4) : 0u;
+      }
+    } else {
+      for (int b = threadIdx.x; b < row_bytes; b += 256) {
+        const int tx = b / 24, c = b - 24 * tx;
+        const uint32_t slot = trow[tx];
+        dst[b] = slot ? erow[size_t(slot - 1u) * kTileEntryBytes + c] : uint8_t(0);
+      }
+    }
+  }
+}
+
 thread_local std::string g_last_error;
 
 }  // namespace
@@ -2314,6 +2444,14 @@ struct rt_ctx {
   bool occluder_table = true;    // RT_OPT_OCCLUDER_TABLE: false = every sphere is a candidate for every object
   bool tile_flush = true;        // RT_OPT_TILE_FLUSH: false = the stream kernel stores finished pixels one by one
   unsigned long long host_primaries = 0;  // primary rays of the visibility pass (one per pixel and sample), counted here
+  // the last render call (rt_compact_tiles): its frames, their tiling, and whether the occupancy bits of ONE launch
+  // describe the whole batch
+  struct LastBatch {
+    const uint8_t* out_rgb = nullptr;
+    TileGeom g{};
+    int occ_words = 0;
+    bool occ_valid = false;
+  } last;
   DevLights lights{};
   std::string err;
 };
@@ -2595,6 +2733,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     }
   }
 
+  ctx->last = rt_ctx::LastBatch();
   RenderParams p{};
   p.L = ctx->lights;
   p.width = width; p.height = height;
@@ -2684,6 +2823,13 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     per_frame = unsigned((w.nx + kTileW - 1) / kTileW) * unsigned((w.n_rows + kTileH - 1) / kTileH);
   }
 
+  if (out_rgb && !ws) {   // what rt_compact_tiles needs to know about this batch
+    ctx->last.out_rgb = out_rgb;
+    ctx->last.g = TileGeom{w.nx, w.n_rows, n_frames, p.tiles8_x, p.tiles8_y, p.tile_pitch, frame_px};
+    ctx->last.occ_words = occ_words;
+    // (one launch pair for the whole batch, or MULTI's one stream launch: the bits cover every sample's hits)
+    ctx->last.occ_valid = stream_kernel && n_frames <= max_batch && (samples == 1 || multi);
+  }
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
     const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots) : pixel_lds(ctx->n_spheres);
@@ -3162,6 +3308,57 @@ int rt_scatter_rows_frames(rt_ctx* ctx, const uint8_t* gathered, int64_t rank_st
   hipLaunchKernelGGL(rt_scatter_rows_kernel, dim3(gx, unsigned(height), unsigned(n_frames)), dim3(256), 0, ctx->stream,
                      gathered, (long long)rank_stride_bytes, n_ranks, width, height, tile_rows, out_rgb, vec4,
                      (long long)frame_stride_bytes, (long long)height * row_bytes);
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_compact_tiles(rt_ctx* ctx, const uint8_t* slab, uint8_t* entries, uint32_t* count_dev, int capacity_tiles) {
+  if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
+  if (!slab || !entries || !count_dev || capacity_tiles < 0) return fail(ctx, RT_EINVAL, "rt_compact_tiles: bad argument");
+  if (ctx->last.out_rgb != slab || !slab)
+    return fail(ctx, RT_ESTATE, "rt_compact_tiles: `slab` is not the frame buffer the last render call on this context wrote");
+  const TileGeom& g = ctx->last.g;
+  const long long total = (long long)g.tile_pitch * g.tiles8_y * g.n_frames;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(uint32_t), ctx->stream));
+  if (total == 0) return RT_OK;
+  const dim3 grid(unsigned((total + 255) / 256));
+  const uint32_t* occ = reinterpret_cast<const uint32_t*>(ctx->d_chunk) + kTileCounters * 32;
+  if (ctx->last.occ_valid)
+    hipLaunchKernelGGL(rt_compact_tiles_kernel<false>, grid, dim3(256), 0, ctx->stream, slab, g, occ, ctx->last.occ_words,
+                       entries, count_dev, (unsigned int)capacity_tiles);
+  else
+    hipLaunchKernelGGL(rt_compact_tiles_kernel<true>, grid, dim3(256), 0, ctx->stream, slab, g, (const uint32_t*)nullptr, 0,
+                       entries, count_dev, (unsigned int)capacity_tiles);
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_place_tiles(rt_ctx* ctx, const uint8_t* entries, const uint32_t* counts_dev, int n_ranks, int capacity_tiles,
+                   int n_frames, int width, int height, int tile_rows, uint32_t* table, int64_t table_words,
+                   uint8_t* out_rgb) {
+  if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
+  if (!entries || !counts_dev || !table || !out_rgb) return fail(ctx, RT_EINVAL, "rt_place_tiles: NULL argument");
+  if (n_ranks < 1 || capacity_tiles < 0 || n_frames < 1 || n_frames > 65535 || width <= 0 || height <= 0 || height > 65535 ||
+      tile_rows < 1)
+    return fail(ctx, RT_EINVAL, "rt_place_tiles: bad argument");
+  const int rows_max = rows_owned(height, tile_rows, 0, n_ranks);            // rank 0 owns the most rows
+  const long long ids_per_rank = (long long)(((width + 7) / 8) | 1) * ((rows_max + 7) / 8) * n_frames;
+  if (table_words < ids_per_rank * n_ranks)
+    return fail(ctx, RT_EINVAL, "rt_place_tiles: table holds %lld words, %lld needed", (long long)table_words,
+                (long long)(ids_per_rank * n_ranks));
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemsetAsync(table, 0, size_t(ids_per_rank) * size_t(n_ranks) * sizeof(uint32_t), ctx->stream));
+  if (capacity_tiles > 0) {
+    hipLaunchKernelGGL(rt_index_tiles_kernel, dim3(unsigned(std::min(1024, (capacity_tiles + 255) / 256)), unsigned(n_ranks)), dim3(256), 0,
+                       ctx->stream, entries, counts_dev, capacity_tiles, ids_per_rank, table);
+    RT_HIP(ctx, hipGetLastError());
+  }
+  const long long row_bytes = (long long)width * 3;
+  const int vec4 = (row_bytes % 4 == 0) && (reinterpret_cast<uintptr_t>(out_rgb) % 4 == 0) && (reinterpret_cast<uintptr_t>(entries) % 4 == 0);
+  hipLaunchKernelGGL(rt_place_tiles_kernel, dim3(unsigned((height + 7) / 8), unsigned(n_frames)),
+                     dim3(256), 0, ctx->stream, entries, (const uint32_t*)table, capacity_tiles, ids_per_rank, n_ranks, width, height,
+                     tile_rows, out_rgb, vec4);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }

@@ -1,17 +1,25 @@
-"""Multi-GPU render: interleaved row tiles per rank, one exchange step (gather to rank 0).
+"""Multi-GPU render: interleaved row tiles per rank, one exchange step (gather to rank 0); frame-parallel
+animation batches (config 5).
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank
-renders tiles t = rank, rank+G, ... of the frame with the same keyed RNG, so the assembled image
-is byte-identical to a 1-GPU render.  The only collective is a fixed-size
-``gather`` of the packed uint8 slabs to rank 0 — G-1 concurrent point-to-point transfers, one per
-xGMI link into GPU 0 — followed by a row scatter on the root (rt_scatter_rows).  The reference has
-no distributed code; its unused ``render_chunk`` tile split (raytracer.py:299-308) is the model.
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank renders tiles
+t = rank, rank+G, ... of the frame with the same keyed RNG, so the assembled image is byte-identical to a
+1-GPU render for scenes without refraction (refractive scenes sum tree nodes with float atomics: equal up to
+summation order, i.e. <= 1/255 on a few pixels, run to run as across GPU counts).  The only
+collective on the data path is a fixed-size ``gather`` to rank 0 — G-1 concurrent point-to-point transfers, one
+per xGMI link into GPU 0 — followed by the placement on the root.  The reference has no distributed code; its
+unused ``render_chunk`` tile split (raytracer.py:299-308) is the model.  RCCL itself has not run yet (one GPU
+per development box): the collectives here have met gloo only.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from .tiling import DEFAULT_TILE_ROWS, local_rows, max_local_rows
+
+
+def _staged(t, dist, group) -> bool:
+    """Device tensors under gloo (the one-GPU rehearsal of the N > 1 path): collectives go through host memory."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def gather_row_tiles(local, width: int, height: int, tile_rows: int, group=None, renderer=None,
@@ -60,57 +68,68 @@ def gather_row_tiles(local, width: int, height: int, tile_rows: int, group=None,
 
 
 class BatchExchange:
-    """Double-buffered exchange of frame batches: the gather of batch i runs (on the collective's own
-    stream) while batch i + 1 is rendered, and the root places batch i after it has launched batch i + 1.
+    """Pipelined exchange of frame batches: while batch i + 1 is rendered, batch i travels (on the collective's
+    own stream), and the root places a batch after it has launched later ones.
 
     Per step every rank calls ``slab = ex.slab(i)``, renders its row tiles of the batch into it, then
-    ``ex.submit(i)``.  ``ex.drain()`` finishes what is in flight.  ``place(gathered, i)`` runs on the root
-    when batch i has arrived (``gathered``: [world, F, slab_bytes]).  Buffers: two slabs per rank, two
-    gather buffers on the root.  With ``world == 1`` the slab is handed to ``place`` directly.
-    Works with nccl (GPU tensors) and gloo (CPU tensors; used by the CPU tests of this logic).
+    ``ex.submit(i)``; ``ex.drain()`` finishes what is in flight.  Works with nccl (GPU tensors) and gloo (CPU
+    tensors: the CPU tests of this logic; GPU tensors are staged through host memory: one-GPU rehearsal).
 
-    ``sparse=True`` sends only what is not black.  The exchange, not the rays, bounds N > 1 (one GPU renders
-    several times what an xGMI link carries), and most of a frame is sky: every rank keeps the
-    32-byte segments of its slab that hold a non-zero byte (19 % of config 2), the ranks agree on the largest
-    count (one tiny all_gather), and the same fixed-size ``gather`` moves [count_max, 5] int64 rows — segment
-    number + 32 bytes — instead of the slab; the root zero-fills its gather buffer and puts the segments back
-    before ``place`` runs.  Lossless: ``place`` sees the same bytes either way (tests).  Needs the batch's
-    bytes to be a multiple of 32 (else the dense path is used)."""
+    Dense (default): one fixed-size ``gather`` of the slabs; ``place(gathered, i)`` runs on the root when batch i
+    has arrived (``gathered``: [world, F, slab_bytes]).  With ``world == 1`` the slab goes to ``place`` directly.
 
-    def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0,
-                 sparse: bool = False, place_segments=None):
+    Sparse (``compact`` and ``place_tiles`` given — bench.py's N > 1 default): only occupied 8x8 tiles travel.  The
+    exchange, not the rays, bounds N > 1 (one GPU renders several times what an xGMI link carries),
+    and most of a frame is background.  ``compact(slab, entries, count)`` (Renderer.compact_tiles: a HIP kernel
+    driven by the occupancy bits the render left behind) packs them into ``entries`` [capacity, entry_bytes] and
+    leaves their number on the device — nothing is read back, so a rank launches render i + 1 without waiting for
+    render i.  Three stages, one per submit:
+      submit(i):   compact batch i; all ranks exchange their counts (a tiny all_gather, asynchronous);
+      submit(i+1): the counts of batch i are read (render i + 1 is queued already, so the GPU stays busy while the
+                   host waits) and ONE gather moves [max count, entry_bytes] per rank — instead of the slab;
+      submit(i+2): ``place_tiles(entries [world, max count, entry_bytes], counts [world] (device), i)`` on the root
+                   (Renderer.place_tiles: one pass over the frames, black where no tile lands).
+    Buffers: two slabs and three entry buffers per rank (a batch's entries live until its gather is done)."""
+
+    def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0, *,
+                 compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.slabs = [torch.zeros((n_frames, slab_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.sparse = bool(sparse) and self.world > 1 and (n_frames * slab_bytes) % 32 == 0
-        # sparse with ``place_segments(rows, counts, step)``: the root hands the gathered [world, count_max, 5]
-        # segment rows to the caller as they are (see segments_to_frames) and keeps no dense gather buffer
-        self.place_segments = place_segments if self.sparse else None
-        self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
-                         for _ in range(2)] if (self.rank == dst and self.world > 1 and self.place_segments is None) \
-            else [None, None]
-        self.pending = [None, None]      # (work handle, step[, segments, counts]) of the batch in flight in each buffer
+        self.sparse = compact is not None
+        if self.sparse and (place_tiles is None or not capacity):
+            raise ValueError("the sparse exchange needs compact, place_tiles and the capacity in tiles")
+        self.compact, self.place_tiles, self.entry_bytes = compact, place_tiles, entry_bytes
+        if self.sparse:
+            self.entries = [torch.empty((capacity, entry_bytes), dtype=torch.uint8, device=device) for _ in range(3)]
+            self.count = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(3)]
+            self.capacity = int(capacity)
+            self.gathered = [None, None]
+        else:
+            self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
+                             for _ in range(2)] if (self.rank == dst and self.world > 1) else [None, None]
+        self.pending = [None, None]      # dense: (work handle, step) of the batch in flight in each buffer
+        self.stage = {}                  # sparse: step -> state of a batch between its compaction and its placement
         self.sent_bytes = 0              # bytes this rank handed to the gather so far (either path)
 
     def slab(self, step: int):
-        self._finish(step & 1)           # the batch that used this buffer two steps ago must be gone
-        return self.slabs[step & 1]
+        if not self.sparse:
+            self._finish(step & 1)       # the batch that used this buffer two steps ago must be gone
+        return self.slabs[step & 1]      # (sparse: compact(step - 2) was queued before this render on the same stream)
 
+    # ---- dense -------------------------------------------------------------------------------
     def submit(self, step: int):
+        if self.sparse:
+            return self._submit_sparse(step)
         b = step & 1
         if self.world == 1:
             self.place(self.slabs[b].unsqueeze(0), step)
             return
-        if self.sparse:
-            self._submit_sparse(step)
-            return
         self.sent_bytes += self.slabs[b].numel()
-        if self.slabs[b].is_cuda and self.dist.get_backend(self.group) == "gloo":
-            # rehearsal of the N > 1 path on one GPU (bench.py RT_BENCH_BACKEND=gloo): gloo has no gather for
-            # device tensors, so the slabs go through host memory, synchronously
+        if _staged(self.slabs[b], self.dist, self.group):
             import torch
             host = self.slabs[b].cpu()
             parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
@@ -125,92 +144,89 @@ class BatchExchange:
         self.pending[b] = (work, step)
         self._finish(1 - b)              # the previous batch: its gather overlapped this batch's render
 
-    def _submit_sparse(self, step: int):
-        import torch
-        b = step & 1
-        dist, slab = self.dist, self.slabs[b]
-        staged = slab.is_cuda and dist.get_backend(self.group) == "gloo"   # one-GPU rehearsal: through host memory
-        seg = slab.view(-1).view(torch.int64).view(-1, 4)                  # 32-byte segments
-        nz = (seg != 0).any(1).nonzero().squeeze(1)                        # (waits for the batch to be rendered)
-        n = int(nz.numel())
-        cdev = "cpu" if staged else slab.device
-        mine = torch.tensor([n], dtype=torch.int64, device=cdev)
-        every = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(self.world)]
-        dist.all_gather(every, mine, group=self.group)
-        counts = [int(c) for c in torch.cat(every).tolist()]
-        nmax = max(counts)
-        self.sent_bytes += nmax * 40
-        work = rows = None
-        if nmax:
-            send = torch.empty((nmax, 5), dtype=torch.int64, device=slab.device)
-            send[:n, 0] = nz
-            send[:n, 1:] = seg.index_select(0, nz)
-            if n < nmax:
-                send[n:].zero_()
-            if staged:
-                host = send.cpu()
-                parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
-                dist.gather(host, parts, dst=self.dst, group=self.group)
-                if self.rank == self.dst:
-                    rows = torch.stack(parts).to(slab.device)
-            else:
-                if self.rank == self.dst:
-                    rows = torch.empty((self.world, nmax, 5), dtype=torch.int64, device=slab.device)
-                work = dist.gather(send, list(rows.unbind(0)) if self.rank == self.dst else None, dst=self.dst,
-                                   group=self.group, async_op=True)
-        self.pending[b] = (work, step, rows, counts, send if nmax else None)
-        self._finish(1 - b)
-
     def _finish(self, b: int):
         if self.pending[b] is None:
             return
-        work, step = self.pending[b][:2]
-        extra = self.pending[b][2:]
+        work, step = self.pending[b]
         self.pending[b] = None
         if work is not None:
             work.wait()                  # nccl: the current stream waits; gloo: the host does
         if self.rank == self.dst:
-            if extra and self.place_segments is not None:
-                self.place_segments(extra[0], extra[1], step)
-                return
-            if extra:                    # sparse: zero-fill, then put every rank's segments back
-                import torch
-                rows, counts = extra[0], extra[1]
-                dense = self.gathered[b].view(self.world, -1).view(torch.int64).view(self.world, -1, 4)
-                dense.zero_()
-                for r, k in enumerate(counts):
-                    if k:
-                        dense[r].index_copy_(0, rows[r, :k, 0], rows[r, :k, 1:])
             self.place(self.gathered[b], step)
 
+    # ---- sparse ------------------------------------------------------------------------------
+    def _submit_sparse(self, step: int):
+        import torch
+        b3 = step % 3
+        assert step - 3 not in self.stage, "a batch's entries are still in flight: drain() or submit in order"
+        dist, world = self.dist, self.world
+        self.compact(self.slabs[step & 1], self.entries[b3], self.count[b3])
+        st = dict(b3=b3, counts=None, work=None, nmax=None, gathered=None)
+        if world == 1:
+            st["counts"] = self.count[b3]
+        elif _staged(self.count[b3], dist, self.group):
+            every = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(every, self.count[b3].cpu(), group=self.group)
+            st["counts"] = torch.cat(every).to(self.count[b3].device)
+        else:
+            st["counts"] = torch.empty(world, dtype=torch.int32, device=self.count[b3].device)
+            st["work"] = dist.all_gather_into_tensor(st["counts"], self.count[b3], group=self.group, async_op=True) \
+                if dist.get_backend(self.group) != "gloo" else \
+                dist.all_gather(list(st["counts"].split(1)), self.count[b3], group=self.group, async_op=True)
+        self.stage[step] = st
+        self._gather_stage(step - 1)
+        self._place_stage(step - 2)
+
+    def _gather_stage(self, step: int):
+        """The counts of batch `step` are in: one gather of [max count, entry_bytes] per rank."""
+        import torch
+        st = self.stage.get(step)
+        if st is None or st["nmax"] is not None:
+            return
+        if st["work"] is not None:
+            st["work"].wait()
+            st["work"] = None
+        counts = [int(c) for c in st["counts"].tolist()]          # (host reads the device: later renders are queued)
+        if max(counts) > self.capacity:
+            raise RuntimeError(f"sparse exchange: {max(counts)} occupied tiles exceed the capacity of {self.capacity}")
+        nmax = st["nmax"] = max(counts)
+        self.sent_bytes += nmax * self.entry_bytes + 4
+        send = self.entries[st["b3"]][:max(nmax, 1)]
+        dist, world = self.dist, self.world
+        if world == 1:
+            st["gathered"] = send.unsqueeze(0)
+        elif _staged(send, dist, self.group):
+            host = send.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if self.rank == self.dst else None
+            dist.gather(host, parts, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                st["gathered"] = torch.stack(parts).to(send.device)
+        else:
+            if self.rank == self.dst:
+                st["gathered"] = torch.empty((world, max(nmax, 1), self.entry_bytes), dtype=torch.uint8, device=send.device)
+            st["work"] = dist.gather(send, list(st["gathered"].unbind(0)) if self.rank == self.dst else None,
+                                     dst=self.dst, group=self.group, async_op=True)
+
+    def _place_stage(self, step: int):
+        st = self.stage.get(step)
+        if st is None:
+            return
+        self._gather_stage(step)
+        if st["work"] is not None:
+            st["work"].wait()
+        del self.stage[step]
+        if self.rank == self.dst:
+            self.place_tiles(st["gathered"], st["counts"], step)
+
     def drain(self):
+        if self.sparse:
+            for step in sorted(self.stage):
+                self._place_stage(step)
+            return
         # in submission order
         order = sorted((p[1], b) for b, p in enumerate(self.pending) if p is not None)
         for _, b in order:
             self._finish(b)
-
-
-def segments_to_frames(rows, counts, frames_out, width: int, height: int, tile_rows: int, rows_max: int):
-    """Root side of the sparse exchange without a dense intermediate: ``rows`` [world, count_max, 5] int64 (segment
-    number within the sender's [F, rows_max, W * 3] slab + its 32 bytes; None when every count is 0) go straight
-    to their place in ``frames_out`` uint8 [F, H, W, 3], which is zero-filled first.  Needs W * 3 % 32 == 0."""
-    import torch
-    world = len(counts)
-    spr = width * 3 // 32                       # segments per image row
-    assert width * 3 % 32 == 0 and frames_out.is_contiguous()
-    out = frames_out.view(-1).view(torch.int64).view(-1, 4)
-    out.zero_()
-    for r, k in enumerate(counts):
-        if not k:
-            continue
-        rowmap = torch.from_numpy(local_rows(height, tile_rows, r, world).astype(np.int64)).to(rows.device)
-        s = rows[r, :k, 0]
-        f = torch.div(s, rows_max * spr, rounding_mode="floor")
-        rem = s - f * (rows_max * spr)
-        lrow = torch.div(rem, spr, rounding_mode="floor")
-        dest = (f * height + rowmap[lrow]) * spr + (rem - lrow * spr)
-        out.index_copy_(0, dest, rows[r, :k, 1:])
-    return frames_out
 
 
 def render_distributed(renderer, width, height, samples=1, *, tile_rows=DEFAULT_TILE_ROWS,
@@ -242,6 +258,57 @@ def make_buffers(renderer, width, height, tile_rows, world, rank):
     return b
 
 
+# ---- frame-parallel animation batches (BASELINE config 5) ------------------------------------------------------
 def frames_of_rank(n_frames: int, rank: int, world: int) -> np.ndarray:
     """Frame-parallel animation (config 5): frame f -> rank f mod G."""
     return np.arange(rank, n_frames, world)
+
+
+def render_frames_parallel(renderer, cameras, seeds, width, height, samples=1, *, group=None, out=None, **kw):
+    """Config 5: this rank renders frames rank, rank + G, ... of the animation WHOLE (``render`` called per frame,
+    raytracer.py:310-325 / :334, batched into launches); no exchange until ``gather_frames``.  ``cameras`` may be
+    the full list (indexed here) or a packed rt_camera array of this rank's frames.  Returns (uint8 tensor
+    [n_local, H, W, 3] on this rank's GPU, the frame numbers it holds)."""
+    import ctypes
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    seeds = list(seeds)
+    mine = frames_of_rank(len(seeds), rank, world)
+    cams = cameras if isinstance(cameras, ctypes.Array) else [cameras[int(f)] for f in mine]
+    local = renderer.render_frames(cams, [seeds[int(f)] for f in mine], width, height, samples, out=out, **kw)
+    return local, mine
+
+
+def gather_frames(local, n_frames: int, group=None, dst: int = 0, out=None):
+    """The one exchange of a frame-parallel batch: every rank's frames to ``dst`` -> [n_frames, H, W, 3] in frame
+    order (None elsewhere).  One fixed-size gather of ceil(n_frames / G) frames per rank (ranks with one frame
+    fewer pad)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    shape = tuple(local.shape[1:])
+    if out is None and rank == dst:
+        out = torch.empty((n_frames,) + shape, dtype=local.dtype, device=local.device)
+    if world == 1:
+        out.copy_(local)
+        return out
+    n_max = -(-n_frames // world)
+    send = local
+    if local.shape[0] < n_max:
+        send = torch.zeros((n_max,) + shape, dtype=local.dtype, device=local.device)
+        send[:local.shape[0]].copy_(local)
+    if _staged(send, dist, group):
+        host = send.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+        dist.gather(host, parts, dst=dst, group=group)
+        gathered = torch.stack(parts).to(local.device) if rank == dst else None
+    else:
+        gathered = torch.empty((world, n_max) + shape, dtype=local.dtype, device=local.device) if rank == dst else None
+        dist.gather(send.contiguous(), list(gathered.unbind(0)) if rank == dst else None, dst=dst, group=group)
+    if rank != dst:
+        return None
+    for r in range(world):
+        k = len(frames_of_rank(n_frames, r, world))
+        if k:
+            out[r::world].copy_(gathered[r, :k])
+    return out

@@ -259,6 +259,35 @@ class Renderer:
                                                        width, height, tile_rows, out.data_ptr()))
         return out
 
+    def compact_tiles(self, slab, entries, count):
+        """Sender side of the sparse exchange (rt_compact_tiles): the occupied 8x8 tiles of the batch the last
+        render call wrote into ``slab`` -> ``entries`` uint8 [capacity, TILE_ENTRY_BYTES], their number ->
+        ``count`` (device uint32/int32 [1]).  Nothing is read back."""
+        torch = _torch()
+        if entries.dtype != torch.uint8 or entries.dim() != 2 or entries.shape[1] != _lib.TILE_ENTRY_BYTES \
+                or not entries.is_contiguous() or count.numel() != 1 or count.element_size() != 4:
+            raise ValueError("entries must be uint8 [capacity, TILE_ENTRY_BYTES] (contiguous), count one 32-bit word")
+        self._check(self._L.rt_compact_tiles(self._h, slab.data_ptr(), entries.data_ptr(), count.data_ptr(),
+                                             int(entries.shape[0])))
+
+    def place_tiles(self, entries, counts, width, height, tile_rows, out, table=None):
+        """Root side (rt_place_tiles): gathered ``entries`` uint8 [n_ranks, capacity, TILE_ENTRY_BYTES] and ``counts``
+        (device, 32-bit, [n_ranks]) -> ``out`` uint8 [F, H, W, 3], black where no entry covers a tile."""
+        torch = _torch()
+        from .tiling import max_local_rows
+        n_ranks, cap = int(entries.shape[0]), int(entries.shape[1])
+        nf = int(out.shape[0])
+        _check_out(out, (nf, height, width, 3), torch.uint8, self.device)
+        need = n_ranks * nf * (((width + 7) // 8) | 1) * ((max_local_rows(height, tile_rows, n_ranks) + 7) // 8)
+        if table is None or table.numel() < need:
+            table = self._alloc((need,), torch.int32)
+        if not entries.is_contiguous() or counts.element_size() != 4 or counts.numel() != n_ranks:
+            raise ValueError("entries must be contiguous, counts 32-bit [n_ranks]")
+        self._check(self._L.rt_place_tiles(self._h, entries.data_ptr(), counts.data_ptr(), n_ranks, cap, nf, int(width),
+                                           int(height), int(tile_rows), table.data_ptr(), int(table.numel()),
+                                           out.data_ptr()))
+        return table
+
     def ray_counts(self) -> dict:
         """{'primary','reflection','shadow','shaded_hits','total'} since the last reset (syncs)."""
         a = (ctypes.c_uint64 * 4)()

@@ -60,40 +60,65 @@ def test_gather_row_tiles_gloo(world, w, h, tile_rows):
 
 
 def _sparse_exchange_worker(rank, world, port, q):
-    """Mostly black slabs with a different number of lit segments on every rank and step (also none at all)."""
+    """BatchExchange's sparse pipeline on CPU tensors: mostly black slabs with a different number of lit tiles on
+    every rank and step (also none at all); compact / place_tiles are the numpy stand-ins of tests/tile_exchange_ref
+    (the HIP entry points need a GPU: tests below)."""
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import tile_exchange_ref as ref
+        from raytracer_amd import tiling
         from raytracer_amd.distributed import BatchExchange
-        F, nbytes, steps = 4, 96 * 5, 6
+        F, w, h, tr, steps = 3, 40, 37, 8, 7
+        rows_max = tiling.max_local_rows(h, tr, world)
+        n_rows = tiling.local_row_count(h, tr, rank, world)
+
+        def frames_of(step):
+            g = np.random.default_rng(100 + step)
+            fr = np.zeros((F, h, w, 3), np.uint8)
+            k = 0 if step == 2 else int(g.integers(1, 60))
+            ys, xs, fs = g.integers(0, h, k), g.integers(0, w, k), g.integers(0, F, k)
+            fr[fs, ys, xs] = g.integers(1, 256, (k, 3))
+            if step == 5:
+                fr[0, 0, 0] = 9; fr[-1, -1, -1] = 7          # first and last pixel
+            return fr
 
         def slab_of(step, r):
-            g = torch.Generator().manual_seed(1000 * step + r)
-            t = torch.zeros(F * nbytes, dtype=torch.uint8)
-            k = 0 if (step == 2 or (step == 4 and r == 0)) else int(torch.randint(1, 40, (1,), generator=g))
-            pos = torch.randint(0, F * nbytes, (k,), generator=g)
-            t[pos] = torch.randint(1, 256, (k,), generator=g).to(torch.uint8)
-            if step == 5:
-                t[-1] = 7; t[0] = 9          # first and last segment
-            return t.view(F, nbytes)
+            rows = tiling.local_rows(h, tr, r, world)
+            sl = np.zeros((F, rows_max, w, 3), np.uint8)
+            sl[:, :len(rows)] = frames_of(step)[:, rows]
+            if step == 4 and r == 0:
+                sl[:] = 0                                      # a rank with nothing to send
+            return sl
+
+        def compact(slab, entries, count):
+            e, n = ref.compact(slab.view(F, rows_max, w, 3).numpy(), n_rows, w)
+            entries[:n] = torch.from_numpy(e)
+            count[0] = n
 
         placed = []
 
-        def place(gathered, step):
-            exp = torch.stack([slab_of(step, r) for r in range(world)])
-            placed.append((step, bool(torch.equal(gathered, exp))))
+        def place_tiles(entries, counts, step):
+            got = ref.place(entries.numpy(), counts.numpy(), F, w, h, tr)
+            exp = frames_of(step)
+            if step == 4:
+                exp[:, tiling.local_rows(h, tr, 0, world)] = 0
+            placed.append((step, bool(np.array_equal(got, exp))))
 
-        ex = BatchExchange(F, nbytes, "cpu", place, sparse=True)
+        ex = BatchExchange(F, rows_max * w * 3, "cpu", None, compact=compact, place_tiles=place_tiles,
+                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8))
         assert ex.sparse
         for i in range(steps):
-            ex.slab(i).copy_(slab_of(i, rank))
+            ex.slab(i).copy_(torch.from_numpy(slab_of(i, rank)).view(F, -1))
             ex.submit(i)
         ex.drain()
-        assert ex.sent_bytes < steps * F * nbytes / 2          # (dense: steps * F * nbytes)
-        assert not BatchExchange(3, 40, "cpu", place, sparse=True).sparse   # 120 bytes: not a multiple of 32 -> dense
+        assert ex.sent_bytes < steps * F * rows_max * w * 3 / 2      # (dense: the whole slabs)
         if rank == 0:
             q.put(placed)
+        else:
+            assert placed == []
     finally:
         dist.destroy_process_group()
 
@@ -142,7 +167,8 @@ def test_batch_exchange_pipeline_gloo(world):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sparse_batch_exchange_gloo(world):
-    """BatchExchange(sparse=True): only non-black 32-byte segments travel; the root sees the same bytes."""
+    """BatchExchange's sparse mode: only occupied tiles travel, three pipelined stages; the root assembles the
+    same frames."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -153,35 +179,7 @@ def test_sparse_batch_exchange_gloo(world):
         p.join(120)
         assert p.exitcode == 0
     placed = q.get(timeout=5)
-    assert [s for s, _ in placed] == list(range(6)) and all(ok for _, ok in placed)
-
-
-def test_segments_to_frames_matches_row_placement():
-    """segments_to_frames puts the 32-byte segments of every rank's slab where the dense path's row placement
-    puts the rows (CPU tensors; ragged last tile, ranks with fewer rows than rows_max)."""
-    from raytracer_amd import tiling
-    from raytracer_amd.distributed import segments_to_frames
-    w, h, tr, F = 32, 45, 8, 3
-    for world in (2, 3, 4):
-        rows_max = tiling.max_local_rows(h, tr, world)
-        g = torch.Generator().manual_seed(world)
-        frames = torch.zeros((F, h, w, 3), dtype=torch.uint8)
-        lit = torch.rand((F, h, w), generator=g) < 0.05
-        frames[lit] = torch.randint(1, 256, (int(lit.sum()), 3), generator=g).to(torch.uint8)
-        rows_all, counts = [], []
-        for r in range(world):
-            lr = torch.from_numpy(tiling.local_rows(h, tr, r, world).astype("int64"))
-            slab = torch.zeros((F, rows_max, w * 3), dtype=torch.uint8)
-            slab[:, :len(lr)] = frames[:, lr].reshape(F, len(lr), w * 3)
-            seg = slab.view(-1).view(torch.int64).view(-1, 4)
-            nz = (seg != 0).any(1).nonzero().squeeze(1)
-            rows_all.append(torch.cat([nz[:, None], seg[nz]], 1)); counts.append(len(nz))
-        nmax = max(counts)
-        rows = torch.zeros((world, nmax, 5), dtype=torch.int64)
-        for r in range(world):
-            rows[r, :counts[r]] = rows_all[r]
-        out = torch.full((F, h, w, 3), 77, dtype=torch.uint8)
-        assert torch.equal(segments_to_frames(rows, counts, out, w, h, tr, rows_max), frames)
+    assert [s for s, _ in placed] == list(range(7)) and all(ok for _, ok in placed)
 
 
 def test_batch_exchange_single_process():
@@ -204,28 +202,30 @@ def _gpu_exchange_worker(rank, world, port, q, sparse=False):
         from raytracer_amd.distributed import BatchExchange
         from raytracer_amd.render import Renderer
         from raytracer_amd.scenes import generate_scene, orbit_camera
-        w, h, tr, F, steps = 320, 187, 8, (4 if sparse else 5), 3     # (sparse: batch bytes a multiple of 32)
+        w, h, tr, F, steps = 320, 187, 8, 5, 4
         r = Renderer(0)
         r.upload_scene(generate_scene(8, 1, keep_default=True))
         rows_max = tiling.max_local_rows(h, tr, world)
         frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0")
         ok = []
 
+        def check(i):
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
+            ok.append(bool(torch.equal(frames_out, full)))
+
         def place(gathered, i):          # rank 0: assemble batch i and compare it with whole-frame renders
             r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out)
-            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
-            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
-            ok.append(bool(torch.equal(frames_out, full)))
+            check(i)
 
-        def place_segments(rows, counts, i):   # sparse, no dense intermediate: segments straight into image order
-            from raytracer_amd.distributed import segments_to_frames
-            segments_to_frames(rows, counts, frames_out, w, h, tr, rows_max)
-            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
-            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
-            ok.append(bool(torch.equal(frames_out, full)))
+        def place_tiles(entries, counts, i):   # sparse: the HIP placement kernel (black + tiles in one pass)
+            frames_out.fill_(77)
+            r.place_tiles(entries, counts, w, h, tr, frames_out)
+            check(i)
 
-        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place, sparse=bool(sparse),
-                           place_segments=place_segments if sparse == 2 else None)
+        ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place, compact=r.compact_tiles, place_tiles=place_tiles,
+                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8)) if sparse else \
+            BatchExchange(F, rows_max * w * 3, "cuda:0", place)
         assert ex.sparse == bool(sparse)
         for i in range(steps):
             cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
@@ -241,13 +241,13 @@ def _gpu_exchange_worker(rank, world, port, q, sparse=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sparse", [0, 1, 2])     # dense / sparse via dense buffer / sparse straight into the frames
+@pytest.mark.parametrize("sparse", [0, 1])     # dense slabs / occupied tiles only (rt_compact_tiles + rt_place_tiles)
 @pytest.mark.parametrize("world", [2, 3])
 def test_batch_exchange_of_gpu_row_tiles(world, sparse):
     """bench.py's N > 1 step on the GPU: `world` processes (all on cuda:0 here) each render their row tiles
-    of a batch with the HIP library, the slabs are gathered (gloo, staged through host memory — RCCL
-    needs one GPU per rank) and rank 0 places them with rt_scatter_rows_frames: the assembled frames
-    are byte-identical to whole-frame renders."""
+    of a batch with the HIP library, the slabs — or only their occupied tiles — are gathered (gloo, staged
+    through host memory — RCCL needs one GPU per rank) and rank 0 places them with the HIP kernels: the
+    assembled frames are byte-identical to whole-frame renders."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -258,4 +258,79 @@ def test_batch_exchange_of_gpu_row_tiles(world, sparse):
         p.join(170)
         assert p.exitcode == 0
     ok = q.get(timeout=5)
-    assert ok == [True, True, True]
+    assert ok == [True] * 4
+
+
+def _frame_parallel_worker(rank, world, port, q):
+    """Config 5: frame f -> rank f mod G, whole frames, one gather at the end."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd.distributed import gather_frames, render_frames_parallel
+        from raytracer_amd.render import Renderer
+        from raytracer_amd.scenes import generate_scene, orbit_camera
+        w, h, F = 160, 90, 37                                # (37 frames: ranks hold different numbers of them)
+        r = Renderer(0)
+        r.upload_scene(generate_scene(8, 1, keep_default=True))
+        cams = [orbit_camera(f, F) for f in range(F)]
+        local, mine = render_frames_parallel(r, cams, range(F), w, h, 1, max_depth=5)
+        assert list(mine) == list(range(rank, F, world)) and local.shape[0] == len(mine)
+        frames = gather_frames(local, F)
+        if rank == 0:
+            full = r.render_frames(cams, range(F), w, h, 1, max_depth=5)
+            q.put(bool(torch.equal(frames, full)) and bool(frames.any()))
+        else:
+            assert frames is None
+        r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_parallel_animation_gpu(world):
+    """BASELINE config 5's mode end to end: every rank renders its frames of the orbit WHOLE; the gathered
+    batch equals a single-rank render of all frames byte for byte."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frame_parallel_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(170)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def _gather_frames_cpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd.distributed import frames_of_rank, gather_frames
+        F = 11
+        mine = frames_of_rank(F, rank, world)
+        local = torch.stack([torch.full((4, 6, 3), int(f) + 1, dtype=torch.uint8) for f in mine]) if len(mine) else \
+            torch.zeros((0, 4, 6, 3), dtype=torch.uint8)
+        out = gather_frames(local, F)
+        if rank == 0:
+            q.put([int(out[f, 0, 0, 0]) for f in range(F)] == list(range(1, F + 1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_frames_gloo(world):
+    """The final exchange of a frame-parallel batch on CPU tensors: frame order restored, uneven shares."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_frames_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

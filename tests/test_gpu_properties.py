@@ -419,3 +419,62 @@ def test_batched_row_tiles_with_frame_stride(renderer):
                                tile_rows=tr, tile_first=r, tile_stride=G)
     assert torch.equal(renderer.scatter_rows_frames(g2, G, w2, h, tr), full2)
 
+
+
+def test_compact_and_place_tiles_match_numpy(renderer):
+    """rt_compact_tiles / rt_place_tiles (the sparse multi-GPU exchange) against the numpy restatement of their
+    data format: every non-black tile of a rank's slab is among the entries, bit for bit (the occupancy bits may
+    add tiles that were hit but are black), and the root assembles the frames of a whole-frame render.  Ranks are
+    played one after another on one GPU; ragged sizes, widths that are no multiple of 4 (byte paths), row tiles
+    of 5 rows (a rank's 8x8 tiles straddle image row tiles), several samples (occupancy bits of all samples), and
+    the path without occupancy bits (samples as separate launches: tiles are found by looking at the bytes)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tile_exchange_ref as ref
+    import torch
+    from raytracer_amd._lib import TILE_ENTRY_BYTES
+    renderer.upload_scene(generate_scene(8, 1, keep_default=True))
+    F = 3
+    cams = [orbit_camera(5 * f, 64) for f in range(F)]
+    try:
+        for (w, h, tr, G, spp, flush) in ((320, 187, 8, 3, 1, True), (333, 90, 8, 2, 1, True), (64, 48, 5, 3, 1, True),
+                                          (200, 111, 16, 4, 1, True), (320, 187, 8, 1, 1, True), (160, 97, 8, 2, 3, True),
+                                          (160, 97, 8, 2, 3, False), (37, 23, 8, 2, 1, False)):
+            renderer.set_tile_flush(flush)
+            rows_max = tiling.max_local_rows(h, tr, G)
+            cap = F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8)
+            ent, cnt = [], []
+            for r in range(G):
+                slab = torch.zeros((F, rows_max, w, 3), dtype=torch.uint8, device="cuda:0")
+                renderer.render_frames(cams, range(F), w, h, spp, out=slab, tile_rows=tr, tile_first=r, tile_stride=G)
+                entries = torch.full((cap, TILE_ENTRY_BYTES), 0xAB, dtype=torch.uint8, device="cuda:0")
+                count = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+                renderer.compact_tiles(slab, entries, count)
+                n = int(count.item())
+                assert 0 < n <= cap
+                n_rows = tiling.local_row_count(h, tr, r, G)
+                exp, n_exp = ref.compact(slab.cpu().numpy(), n_rows, w)
+                got = entries[:n].cpu().numpy()
+                ids = got[:, :4].copy().view(np.uint32)[:, 0]
+                assert len(set(ids.tolist())) == n                        # every tile once
+                by_id = {int(i): got[k] for k, i in enumerate(ids)}
+                for e in exp:
+                    i = int(e[:4].copy().view(np.uint32)[0])
+                    assert i in by_id and np.array_equal(by_id.pop(i), e), (w, h, r, i)
+                assert all(not v[4:].any() for v in by_id.values())       # extras: hit but black
+                assert n >= n_exp
+                ent.append(entries); cnt.append(n)
+            nmax = max(cnt)
+            gathered = torch.stack([e[:nmax] for e in ent]).contiguous()
+            counts = torch.tensor(cnt, dtype=torch.int32, device="cuda:0")
+            out = torch.full((F, h, w, 3), 77, dtype=torch.uint8, device="cuda:0")
+            renderer.place_tiles(gathered, counts, w, h, tr, out)
+            full = renderer.render_frames(cams, range(F), w, h, spp)
+            assert torch.equal(out, full), (w, h, tr, G, spp, flush)
+            assert np.array_equal(ref.place(gathered.cpu().numpy(), cnt, F, w, h, tr), full.cpu().numpy())
+        # a slab that is not the last render's frame buffer is refused
+        other = torch.zeros((F, rows_max, w, 3), dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(_lib.RtError, match="last render call"):
+            renderer.compact_tiles(other, entries, count)
+    finally:
+        renderer.set_tile_flush(True)

@@ -8,7 +8,7 @@ for pmc in "SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_I
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc $pmc --output-format csv -d "$out/pass$i" -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $wl > "$out/pass$i.log" 2>&1) || { echo "pass $i failed"; tail -3 "$out/pass$i.log"; exit 1; }
+  (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc $pmc --output-format csv -d "$out/pass$i" -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target --workload $wl > "$out/pass$i.log" 2>&1) || { echo "pass $i failed"; tail -3 "$out/pass$i.log"; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, os, sys
