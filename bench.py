@@ -62,6 +62,7 @@ WORKLOADS = {
     "refr": (1920, 1080, 5, 0, True, 5, "8f rank 2: refractive_scene() (default scene + glass) 1920x1080 depth 5"),
     "cubes": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene() (default scene + 3 opaque cubes) 1920x1080 depth 5"),
     "cubes_glass": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene(glass=True) 1920x1080 depth 5"),
+    "refr40": (1920, 1080, 40, 12, False, 5, "8f rank 2: 40 generated spheres, every third of glass, 1920x1080 depth 5"),
 }
 
 
@@ -77,7 +78,12 @@ def build_scene(wl):
     w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
     if wl in ("refr", "cubes", "cubes_glass"):
         return refractive_scene() if wl == "refr" else cube_scene(glass=(wl == "cubes_glass"))
-    return default_scene() if n == 3 else generate_scene(n, sseed, w, h, keep_default=keep)
+    scene = default_scene() if n == 3 else generate_scene(n, sseed, w, h, keep_default=keep)
+    if wl == "refr40":
+        for i, s_ in enumerate(scene["spheres"]):
+            if i % 3 == 0:
+                s_.material.refraction, s_.material.refractive_index = 0.6, 1.4
+    return scene
 
 
 def cpu_baseline(wl, target_s=5.0):

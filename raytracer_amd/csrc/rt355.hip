@@ -110,6 +110,7 @@ struct RenderParams {
   const float4* mat;     // R G B reflection
   const float* spec;     // specular
   const float2* refr;    // refraction, refractive_index (raytracer.py:43); only read by the REFR kernels
+  const uint32_t* glass_bits;  // [ceil(n_spheres / 32)] bit c: sphere c is refractive (REFR kernels' shadow scan)
   const uint32_t* occl;  // [objects][occl_words] bit c of row k: sphere c can shadow some point of object k (host table)
   int occl_words;        // ceil(n_spheres / 32)
   // uniform grid over the spheres for reflection rays of many-sphere scenes (grid_dim = 0: none)
@@ -170,6 +171,10 @@ constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shad
 #define RT_NOW() 0ull
 #endif
 constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (raytracer.py:80)
+#ifndef RT_REFR_BATCH
+#define RT_REFR_BATCH 7
+#endif
+constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: two verdicts per ray (opaque / glass), so fewer rays per batch fit the registers
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
 constexpr int kTileW = 32, kTileH = 8;
@@ -726,6 +731,7 @@ __device__ __forceinline__ void light_colour(const DevLights& L, const LightSums
 template <int MODE, int B, bool REFR = false, bool CUBES = false>
 __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* __restrict__ sg,
                                          const float4* __restrict__ gg, const float2* __restrict__ refr,
+                                         const uint32_t* __restrict__ glass_bits,
                                          const uint32_t* __restrict__ occl_row, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          uint32_t level_key) {
@@ -738,6 +744,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
   float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
   for (int base = 0; base < nrays; base += B) {
     float Lx[B], Ly[B], Lz[B], m[B];
+    float mrf[REFR ? B : 1];   // REFR: the same verdicts for the REFRACTIVE spheres (m: the opaque ones)
+#pragma unroll
+    for (int k = 0; k < (REFR ? B : 1); ++k) mrf[k] = -1.0f;
 #pragma unroll
     for (int k = 0; k < B; ++k) {
       const int j = base + k;
@@ -763,7 +772,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     // work at full VALU rate — hit <=> sign(dl) == 0 and sign(nb) == 0, so `acc &= (dl | nb)`
     // clears acc's sign bit as soon as any sphere is hit (v_min/v_max/v_cmp are half rate on
     // gfx950, v_and/v_or full rate: profiles/r1_ubench_valu_rate.txt).
-    auto test_sphere = [&](const float4 g) {
+    // (REFR: `glass` = 0x80000000 for a refractive sphere, 0 for an opaque one — a set sign bit leaves the other
+    // class's verdicts as they are)
+    auto test_sphere = [&](const float4 g, uint32_t glass = 0u) {
       const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
       const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
 #if RT_SHADOW_CHEAP
@@ -782,7 +793,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
         const float dh = fmaf(nb, nb, -chi);
         const float dlo = dh + thr2;
-        m[k] = __uint_as_float(__float_as_uint(m[k]) & (__float_as_uint(dh) | __float_as_uint(nb)));
+        const uint32_t verdict = __float_as_uint(dh) | __float_as_uint(nb);
+        m[k] = __uint_as_float(__float_as_uint(m[k]) & (REFR ? verdict | glass : verdict));
+        if constexpr (REFR) mrf[k] = __uint_as_float(__float_as_uint(mrf[k]) & (verdict | (glass ^ 0x80000000u)));
         amb |= __float_as_uint(dh) & ~__float_as_uint(dlo);   // sign set: dh < 0 <= dh + 2 thr
         asm volatile("" : "+v"(m[k]), "+v"(amb));   // keep both chains sequential (no reassociation tree)
       }
@@ -796,7 +809,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
           const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
           const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
 #if RT_ACC_BITS
-          m[k] = __uint_as_float(__float_as_uint(m[k]) & (__float_as_uint(dl) | __float_as_uint(nb)));
+          const uint32_t verdict = __float_as_uint(dl) | __float_as_uint(nb);
+          m[k] = __uint_as_float(__float_as_uint(m[k]) & (REFR ? verdict | glass : verdict));
+          if constexpr (REFR) mrf[k] = __uint_as_float(__float_as_uint(mrf[k]) & (verdict | (glass ^ 0x80000000u)));
           asm volatile("" : "+v"(m[k]));   // keep the and-chain sequential (no reassociation tree)
 #else
           m[k] = __builtin_fmaxf(m[k], __builtin_fminf(dl, nb));
@@ -804,21 +819,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         }
       }
     };
-    if constexpr (REFR) {
-      // Scenes with refractive materials: a shadow ray is blocked only if its NEAREST hit is opaque
-      // (raytracer.py:187, :202), so the any-hit shortcut does not apply: one full nearest-hit scan
-      // per ray, as the reference does.
-#pragma unroll
-      for (int k = 0; k < B; ++k) {
-        if (base + k < nrays) {
-          float t;
-          int hi, face;
-          nearest_object<CUBES>(sg, gg, n, nc, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi, face);
-          const bool blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
-          m[k] = blocked ? 0.0f : -1.0f;
-        }
-      }
-    } else
 #if RT_CULL
     // Per-lane sphere culling.  The B rays of a lane leave one point towards one small light, so
     // almost every sphere is far from all of them; but lanes of a wave are unrelated pixels, so no
@@ -885,7 +885,8 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
           if (rel != 0u) {
             const int j = __ffs(int(rel)) - 1;
             rel &= rel - 1u;
-            test_sphere(sg[cbase + j]);
+            if constexpr (REFR) test_sphere(sg[cbase + j], ((glass_bits[word] >> j) & 1u) << 31);
+            else test_sphere(sg[cbase + j]);
           }
         }
       }
@@ -939,6 +940,36 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         if (hit) m[k] = 0.0f;
       }
     }
+    if constexpr (REFR) {
+      // Scenes with refractive materials: a shadow ray is blocked only if its NEAREST hit is opaque
+      // (raytracer.py:187, :202).  The scan above has told, per ray, whether it hits SOME opaque sphere (m) and
+      // whether it hits SOME refractive one (mrf) — the any-hit tests of the opaque path, over the same culled
+      // candidates, no root taken.  No opaque hit: lit.  Opaque hits only: blocked.  Both (a ray through glass
+      // towards something solid, or the other way round: rare): the nearest hit decides, found by the full scan
+      // of find_nearest_intersection for that ray.  Cubes (their line rule, :137, :162) are tested ray by ray.
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        bool solid = int(__float_as_uint(m[k])) >= 0, glass = int(__float_as_uint(mrf[k])) >= 0;
+        if constexpr (CUBES) {
+          const float ix = frcp(Lx[k]), iy = frcp(Ly[k]), iz = frcp(Lz[k]);
+          for (int c = 0; c < nc; ++c) {
+            float t;
+            int face;
+            if (cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], sx, sy, sz, Lx[k], Ly[k], Lz[k], ix, iy, iz, t, face)) {
+              if (refr[n + c].x > 0.0f) glass = true; else solid = true;
+            }
+          }
+        }
+        bool blocked = solid && !glass;
+        if (solid && glass && base + k < nrays) {
+          float t;
+          int hi, face;
+          nearest_object<CUBES>(sg, gg, n, nc, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi, face);
+          blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
+        }
+        m[k] = blocked ? 0.0f : -1.0f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < B; ++k) {
       const float ndl = fmaf(nz, Lz[k], fmaf(ny, Ly[k], nx * Lx[k]));
@@ -986,7 +1017,7 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-  const LightSums w = lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+  const LightSums w = lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, nullptr, p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                level_key);
   float4 m;
   float spec;
@@ -1902,20 +1933,27 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
         float fpx = 0.f, fpy = 0.f, fpz = 0.f, fdx = 0.f, fdy = 0.f, fdz = 0.f, ftr = 0.f, ftg = 0.f, ftb = 0.f;
         uint32_t meta_r = 0u, meta_f = 0u;
         if (have) {
-          const RenderParams& p = params_here();
-          const int level = meta_level(meta), rframe = meta_frame(meta), idx = meta_object(meta);
           ++n_shade;
-          const float4 m = p.mat[idx];
-          const float spec = p.spec[idx];
-          const float2 rf = p.refr[idx];
-          float nx, ny, nz;
-          surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
-          const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-          float lr, lg, lb;
-          const LightSums lw = lighting<MODE, 1, true, CUBES>(p.L, sg, p.geom, p.refr, nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
-                                  sx, sy, sz, mix(pixel_key, uint32_t(level + 1)));
-          light_colour(p.L, lw, m.x, m.y, m.z, spec, lr, lg, lb);
-          late_state();
+          float nx, ny, nz, sx, sy, sz, lr, lg, lb;
+          float4 m;
+          float2 rf;
+          {
+            const RenderParams& p = params_here();                   // the lights and tables of lighting(): dead after it
+            const int idx = meta_object(meta);
+            surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
+            sx = fmaf(nx, 0.001f, px); sy = fmaf(ny, 0.001f, py); sz = fmaf(nz, 0.001f, pz);
+            const LightSums lw = lighting<MODE, kRefrShadowBatch, true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
+                                    sx, sy, sz, mix(pixel_key, uint32_t(meta_level(meta) + 1)));
+            // (material, record state and the meta word come in BEHIND the shadow loops, as in the opaque path:
+            // the 13-ray batch leaves no registers for them)
+            float spec;
+            LateFromRecord late{p, late_state, q, e, meta, base, lane_here()};
+            late.load(m, spec);
+            rf = p.refr[meta_object(meta)];
+            light_colour(p.L, lw, m.x, m.y, m.z, spec, lr, lg, lb);
+          }
+          const RenderParams& p = params_here();
+          const int level = meta_level(meta), rframe = meta_frame(meta);
           s2 = RT_NOW();
           const float refl = m.w, refr = rf.x;
           const float own = (1.0f - refl) * (1.0f - refr);                   // :249, :254 (1 - 0 = 1 exactly)
@@ -2422,6 +2460,7 @@ struct rt_ctx {
   float grid_min[3] = {0, 0, 0}, grid_inv_cell[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0};
   bool sphere_grid = true;            // RT_OPT_SPHERE_GRID
   int queue_spill = 1;                // RT_OPT_QUEUE_SPILL: 0 off, 1 automatic depth, 2.. = at most that many blocks per wave
+  uint32_t* d_glass_bits = nullptr;   // bit c: sphere c has refraction > 0 (rt_set_refraction; zero after rt_upload_scene)
   uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
@@ -2747,6 +2786,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
   p.cubes = ctx->d_cubes; p.n_cubes = ctx->n_cubes;
   p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32;
+  p.glass_bits = ctx->d_glass_bits;
   p.grid_start = ctx->d_grid_start; p.grid_items = ctx->d_grid_items; p.grid_big = ctx->d_grid_big;
   p.grid_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->grid_dim;
   p.grid_n_big = ctx->grid_n_big;
@@ -2955,6 +2995,8 @@ int rt_create(int device_id, rt_ctx** out) {
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
     return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_glass_bits, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMalloc(&ctx->d_frames, sizeof(FrameRec) * kMaxBatch)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
@@ -2996,6 +3038,7 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_refr) (void)hipFree(ctx->d_refr);
   if (ctx->d_cubes) (void)hipFree(ctx->d_cubes);
   if (ctx->d_occl) (void)hipFree(ctx->d_occl);
+  if (ctx->d_glass_bits) (void)hipFree(ctx->d_glass_bits);
   if (ctx->d_grid_start) (void)hipFree(ctx->d_grid_start);
   if (ctx->d_grid_items) (void)hipFree(ctx->d_grid_items);
   if (ctx->d_grid_big) (void)hipFree(ctx->d_grid_big);
@@ -3108,6 +3151,7 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     ctx->grid_dim = grid.dim;
     ctx->grid_n_big = int(grid.big.size());
   }
+  RT_HIP(ctx, hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32)));
   ctx->n_spheres = n_spheres;
   ctx->has_refr = false;   // Material's defaults (raytracer.py:43) until rt_set_refraction says otherwise
   ctx->n_cubes = 0;        // the object list holds spheres only until rt_set_cubes says otherwise
@@ -3198,6 +3242,12 @@ int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refract
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (n_spheres > 0)
     RT_HIP(ctx, hipMemcpy(ctx->d_refr, h.data(), sizeof(float2) * size_t(n_spheres), hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> bits(RT_MAX_SPHERES / 32, 0u);
+    for (int i = 0; i < n_spheres; ++i)
+      if (refraction[i] > 0.0f) bits[size_t(i >> 5)] |= 1u << (i & 31);
+    RT_HIP(ctx, hipMemcpy(ctx->d_glass_bits, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
+  }
   ctx->has_refr = any;
   return RT_OK;
 }

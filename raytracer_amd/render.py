@@ -79,6 +79,11 @@ class Renderer:
             return self._packed          # the device already holds exactly this scene (and its occluder table)
         lights = p.ct_lights()
         g, m, s = (np.ascontiguousarray(a, np.float32) for a in (p.geom4, p.mat4, p.spec))
+        # From here on the device scene is in flux (rt_upload_scene resets it, rt_set_refraction / rt_set_cubes
+        # complete it): the cache names no scene until all three have succeeded, so a failure midway can never make
+        # a later render of the PREVIOUS scene skip its upload and trace the half-uploaded one.
+        self._packed = None
+        self._uploaded_options = None
         self._check(self._L.rt_upload_scene(self._h, g.ctypes.data, m.ctypes.data, s.ctypes.data,
                                             p.n_spheres, ctypes.byref(lights)))
         if p.has_refraction:      # Material.refraction / .refractive_index (raytracer.py:43, :213-230)

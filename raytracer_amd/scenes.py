@@ -249,6 +249,9 @@ def pack_scene(scene: dict) -> PackedScene:
     sph_pos = [i for i, c in enumerate(is_cube) if not c]
     cube_pos = [i for i, c in enumerate(is_cube) if c]
     n, nc = len(sph_pos), len(cube_pos)
+    if n + 2 * nc > MAX_SPHERES:     # rt_set_cubes' limit (a cube takes two entries of the LDS object list): fail here,
+        raise ValueError(            # before rt_upload_scene has replaced the scene on the device
+            f"scene has {n} spheres and {nc} cubes; spheres + 2 x cubes must not exceed {MAX_SPHERES}")
     geom = np.zeros((n, 4), np.float32)
     mat = np.zeros((n, 4), np.float32)
     spec = np.zeros((n,), np.float32)

@@ -478,3 +478,50 @@ def test_compact_and_place_tiles_match_numpy(renderer):
             renderer.compact_tiles(other, entries, count)
     finally:
         renderer.set_tile_flush(True)
+
+
+def test_failed_upload_never_leaves_a_stale_scene_cache(renderer):
+    """A scene upload that fails midway (here: rt_set_refraction rejects a non-positive refractive index after
+    rt_upload_scene has already replaced the spheres) must not leave the renderer believing that the device still
+    holds the previous scene: the next render of that scene uploads it again and matches a fresh renderer."""
+    import torch
+    from raytracer_amd.scenes import refractive_scene
+    good = generate_scene(8, 1, keep_default=True)
+    renderer.upload_scene(good)
+    ref = renderer.render(160, 90, 1, seed=3)
+    from raytracer_amd.scenes import pack_scene
+    bad = pack_scene(refractive_scene())
+    bad.refr[:, 1] = -1.0                             # (pack_scene itself would refuse this; the library does too, late)
+    with pytest.raises(_lib.RtError):
+        renderer.upload_scene(bad)
+    assert renderer._packed is None
+    renderer.upload_scene(good)                       # (what the module-level render() does before every frame)
+    assert torch.equal(renderer.render(160, 90, 1, seed=3), ref)
+
+
+def test_occluder_table_with_refraction(renderer):
+    """Refractive scenes: shadow rays look for their NEAREST hit (blocked only if it is opaque, raytracer.py:187,
+    :202) among the occluder table's candidates instead of all objects.  Same tree nodes with the table on and
+    off: identical ray counts and hit maps, images equal up to float summation order."""
+    import torch
+    from raytracer_amd.scenes import Material, Sphere, Vector3, cube_scene, refractive_scene
+    many = generate_scene(40, 12)
+    for i, s_ in enumerate(many["spheres"]):
+        if i % 3 == 0:
+            s_.material.refraction, s_.material.refractive_index = 0.6, 1.4
+    cases = [(refractive_scene(), 480, 270, 5), (cube_scene(glass=True), 320, 180, 4), (many, 480, 270, 4)]
+    try:
+        for scene, w, h, D in cases:
+            out = []
+            for on in (True, False):
+                renderer.set_occluder_table(on)
+                renderer.upload_scene(scene)
+                renderer.reset_ray_counts()
+                img, hit = renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=5, return_hit_index=True)
+                out.append((img.to(torch.int16), hit, renderer.ray_counts()))
+            (a, ha, ca), (b, hb, cb) = out
+            assert torch.equal(ha, hb) and ca == cb and ca["total"] > w * h
+            d = (a - b).abs()
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01
+    finally:
+        renderer.set_occluder_table(True)

@@ -182,3 +182,17 @@ def test_occluder_table_is_a_superset_of_brute_force():
         assert not (hit_any & ~bits).any(), "a sphere that is hit is missing from the table"
         if n >= 64:      # and the table is selective: a few candidates per object, not all of them
             assert bits.sum(1).mean() < 0.25 * n
+
+
+def test_pack_scene_enforces_the_cube_limit_before_the_device_is_touched():
+    """rt_set_cubes accepts n_spheres + 2 n_cubes <= RT_MAX_SPHERES; pack_scene raises for anything beyond, so
+    Renderer.upload_scene cannot fail between rt_upload_scene and rt_set_cubes on a scene that is merely too large."""
+    from raytracer_amd.scenes import MAX_SPHERES, Cube, Material, Sphere, Vector3, default_scene, pack_scene
+    m = Material(Vector3(1, 1, 1))
+    sc = default_scene()
+    sc["spheres"] = [Sphere(Vector3(i, 0, -5), 0.1, m) for i in range(MAX_SPHERES - 800)] + \
+                    [Cube(Vector3(i, 1, -5), Vector3(i + 0.5, 1.5, -4.5), m) for i in range(400)]
+    pack_scene(sc)                                   # 1248 + 800 = 2048: fits
+    sc["spheres"].append(Cube(Vector3(0, 3, -5), Vector3(1, 4, -4), m))
+    with pytest.raises(ValueError, match="2 x cubes"):
+        pack_scene(sc)
