@@ -209,6 +209,7 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+
 // wave-uniform reads of the constant sphere tables: address space 4 makes hipcc emit scalar loads
 // (s_load_dwordx4..x16 into SGPRs) — no LDS traffic, no VGPRs, and SGPR operands feed the VALU
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -272,10 +273,32 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const
   best_t = INFINITY;
   best_i = -1;
 #if RT_NEAR_SRC == 2
-  cgeom_t src = as_const(gg);
-#else
-  const float4* src = sg;   // wave-uniform address: LDS broadcast read
+  // Scalar loads: four spheres per turn (64 B), the next four requested before these are tested, so the load's
+  // latency passes under ~60 vector instructions instead of being waited for sphere by sphere.  The list is
+  // padded with eight never-hit spheres (r^2 = -inf, rt_upload_scene), so neither the last block nor the
+  // prefetch behind it needs a bound.
+  {
+    cgeom_t src = as_const(gg);
+    auto test = [&](const float4 s, int i) {
+      const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+      const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
+      const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
+      const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));  // r^2 - |l|^2
+      if (dl >= 0.0f) {
+        const float t = q - fsqrt(dl * inv_a);
+        if (t > 0.0f && t < best_t) { best_t = t; best_i = i; }
+      }
+    };
+    float4 n0 = src[0], n1 = src[1], n2 = src[2], n3 = src[3];
+    for (int i = 0; i < n; i += 4) {
+      const float4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+      n0 = src[i + 4]; n1 = src[i + 5]; n2 = src[i + 6]; n3 = src[i + 7];
+      test(c0, i); test(c1, i + 1); test(c2, i + 2); test(c3, i + 3);
+    }
+    return;
+  }
 #endif
+  const float4* src = sg;   // wave-uniform address: LDS broadcast read
 #pragma unroll 4
   for (int i = 0; i < n; ++i) {
     const float4 s = src[i];
@@ -3116,6 +3139,11 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   RT_HIP(ctx, hipSetDevice(ctx->device));
   // the previous scene may still be in use by launches in flight on the stream
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  {   // eight never-hit spheres behind the list: nearest_hit reads it in blocks of four, one block ahead
+    float pad[8 * 4];
+    for (int i = 0; i < 8; ++i) { pad[4 * i] = pad[4 * i + 1] = pad[4 * i + 2] = 0.0f; pad[4 * i + 3] = -INFINITY; }
+    RT_HIP(ctx, hipMemcpy(ctx->d_geom + n_spheres, pad, sizeof(pad), hipMemcpyHostToDevice));
+  }
   if (n_spheres > 0) {
     RT_HIP(ctx, hipMemcpy(ctx->d_geom, geom4, sizeof(float) * 4 * n_spheres, hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_mat, mat4, sizeof(float) * 4 * n_spheres, hipMemcpyHostToDevice));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on the GPU box: tools/ab.sh "<workloads>" lib1.so lib2.so ...
+# A/B of library builds: tools/ab.sh "<workloads>" lib1.so lib2.so ...   (one line per build and workload)
 wls=$1; shift
 for lib in "$@"; do
   for wl in $wls; do
@@ -7,8 +7,8 @@ for lib in "$@"; do
 import sys, json
 l=sys.stdin.read().strip()
 try:
-    d=json.loads(l); print('$lib', '$wl', 'Mrays/s', round(d['value']), 'kern_ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],4))
+    d=json.loads(l); print('$lib', '$wl', 'Mrays/s', round(d['value']), 'kern_ms', round(d['roofline']['kernel_ms'],3))
 except Exception as e: print('$lib $wl ERR', l[-300:])
-"
+" || exit 1
   done
 done
