@@ -48,6 +48,9 @@ PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 
 # (TCC_EA0_WRREQ x 64 + TCC_EA0_RDREQ x 64 x 2, the guide's gfx950 correction), and the rays of that launch pair.
 # (tools/pmc_constants.py prints these lines from a tools/profile.sh directory.)
 PMC = {
+    "c2": dict(profile="profiles/r2b_c2_rt_{stream,visibility}_kernel.txt", flops=5.701e+11, valu=1.294e+10, salu=5.252e+09, hbm_bytes=1.067e+10, rays=7.863e+09),
+    "t64": dict(profile="profiles/r2b_t64_rt_{stream,visibility}_kernel.txt", flops=8.931e+11, valu=1.575e+10, salu=6.11e+09, hbm_bytes=1.039e+10, rays=6.428e+09),
+    "c4": dict(profile="profiles/r2b_c4_rt_{stream,visibility}_kernel.txt", flops=6.596e+11, valu=1.847e+10, salu=8.027e+09, hbm_bytes=3.453e+09, rays=3.36e+09),
 }
 
 WORKLOADS = {
@@ -87,9 +90,12 @@ def build_scene(wl):
 
 
 def cpu_baseline(wl, target_s=5.0):
-    """Time the oracle (FP64 restatement of the reference) on this host, all cores, on whole frames
-    of the same workload until ~target_s seconds of CPU time have been spent."""
+    """Time the oracle (FP64 restatement of the reference) on this host, all cores, on the same workload until
+    ~target_s seconds have been spent.  A sample "frame" is the whole frame where one costs about what a config-2
+    frame does; bigger workloads (more pixels x spheres x depth) are sampled on a regular pixel lattice of the
+    frame (every k-th pixel of every k-th row), so the ray mix stays the workload's and the run stays bounded."""
     from oracle import cpu_oracle
+    import numpy as np
     w, h, n, sseed, keep, D, _ = WORKLOADS[wl]
     scene = build_scene(wl)
     threads = min(cpu_oracle.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 10**6,
@@ -97,24 +103,32 @@ def cpu_baseline(wl, target_s=5.0):
 
     from raytracer_amd.scenes import pack_scene
     p = pack_scene(scene)
+    cost = (w * h) * max(p.n_spheres, 8) / (1920.0 * 1080.0 * 8.0)
+    k = max(1, int(np.ceil(np.sqrt(cost))))
+    pixels = None
+    if k > 1:
+        ys, xs = np.meshgrid(np.arange(k // 2, h, k), np.arange(k // 2, w, k), indexing="ij")
+        pixels = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
 
     def run_frame(seed, nthreads=None):
         t0 = time.perf_counter()
-        o = cpu_oracle.render_scene(p, w, h, max_depth=D, mode="K", seed=seed,
+        o = cpu_oracle.render_scene(p, w, h, pixels=pixels, max_depth=D, mode="K", seed=seed,
                                     threads=threads if nthreads is None else nthreads)
         dt = time.perf_counter() - t0
         rays = int(o["trace_levels"].sum()) + (1 + p.area_samples) * int(o["hit_levels"].sum())
         return rays, dt
 
-    # whole frames of the workload (seed = frame index) until ~target_s of CPU time is spent
+    # sample frames of the workload (seed = frame index) until ~target_s of CPU time is spent
     rays = frames = 0
     dt = 0.0
     while dt < target_s and frames < 1024:
         r_, d_ = run_frame(frames)
         rays += r_; dt += d_; frames += 1
-    r1, d1 = run_frame(0, 1)     # the same restatement on one thread, one frame
+    r1, d1 = run_frame(0, 1)     # the same restatement on one thread, one sample frame
+    what = "whole frames of the workload" if pixels is None else \
+        f"sample frames of the workload (every {k}th pixel of every {k}th row: {len(pixels)} pixels each)"
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
-                sample=f"{frames} whole frames of the workload ({rays} rays, {dt:.1f} s), FP64, OpenMP",
+                sample=f"{frames} {what} ({rays} rays, {dt:.1f} s), FP64, OpenMP",
                 single_thread_mrays=r1 / d1 / 1e6,
                 python_reference_mrays_1core=PY_REFERENCE_MRAYS)
 

@@ -367,6 +367,10 @@ int run(int n, const int32_t* kind, const float* box_max, const float* center, c
 
 }  // namespace
 
+#ifdef _OPENMP
+static const int g_threads_at_start = omp_get_max_threads();   // at library load
+#endif
+
 extern "C" {
 
 // precision: 0 = double (the oracle), 1 = float (diagnostic).  pixels = NULL renders the full
@@ -422,7 +426,9 @@ int rto_render_pixels(int n, const float* center, const float* radius, const flo
 
 int rto_max_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
+  // the team size OpenMP started with (OMP_NUM_THREADS or the processors), not what an earlier
+  // render's omp_set_num_threads left behind
+  return g_threads_at_start;
 #else
   return 1;
 #endif
