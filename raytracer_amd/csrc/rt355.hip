@@ -2541,6 +2541,10 @@ size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16;
 size_t stream_lds(int n_spheres, bool refr = false, int out = 0) {
   return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * (kBlock / 64);
 }
+// resident workgroups of the stream kernel per CU: one per wave slot of a SIMD, or as many as 160 KB of LDS hold
+unsigned workgroups_per_cu(size_t lds) {
+  return unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
+}
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
 // RN(1/n) for div_exact(): the float nearest to 1/n, chosen by the exact residual |1 - n*r| (n < 2^21
@@ -2780,7 +2784,13 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   // 8-bit frames at one sample per pixel: the stream kernel stages finished pixels per tile and stores whole tiles
   // ... and with 2..64 samples per pixel all of them are traced in ONE launch pair and summed in the slots
-  const int slots = (stream_kernel && ctx->tile_flush && !refr && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
+  int slots = (stream_kernel && ctx->tile_flush && !refr && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
+  // ... unless the slots' LDS would cost a resident workgroup per CU (many-sphere scenes, whose sphere list takes
+  // 16 B per sphere of every workgroup's LDS): config 4 measured 88 Grays/s on three workgroups per CU with
+  // scattered stores against 65 on two with tile stores
+  if (slots == 1 && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 1)) <
+                        workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 0)))
+    slots = 0;
   const bool multi = slots == 2;
   const size_t vis_need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch) *
                           size_t(multi ? samples : 1);   // whole 8x8 tiles, odd pitch; MULTI: a record per sample
@@ -2934,7 +2944,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         // (and never more than the LDS lets stay resident)
-        const unsigned per_cu = unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
+        const unsigned per_cu = workgroups_per_cu(lds);
         const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which

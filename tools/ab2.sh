@@ -4,7 +4,7 @@ wls=$1; shift
 for lib in "$@"; do
   for wl in $wls; do
     for nf in "" 1; do
-    RT_BENCH_NO_TILE_FLUSH=$nf RT355_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-target --workload $wl 2>&1 | tail -1 | python -c "
+    RT_BENCH_NO_TILE_FLUSH=$nf RT355_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-target --workload $wl ${AB_ARGS:-} 2>&1 | tail -1 | python -c "
 import sys, json
 l=sys.stdin.read().strip()
 try:
