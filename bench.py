@@ -50,7 +50,7 @@ PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 
 PMC = {
     "c2": dict(profile="profiles/r2b_c2_rt_{stream,visibility}_kernel.txt", flops=5.701e+11, valu=1.294e+10, salu=5.252e+09, hbm_bytes=1.067e+10, rays=7.863e+09),
     "t64": dict(profile="profiles/r2b_t64_rt_{stream,visibility}_kernel.txt", flops=8.931e+11, valu=1.575e+10, salu=6.11e+09, hbm_bytes=1.039e+10, rays=6.428e+09),
-    "c4": dict(profile="profiles/r2b_c4_rt_{stream,visibility}_kernel.txt", flops=6.596e+11, valu=1.847e+10, salu=8.027e+09, hbm_bytes=3.453e+09, rays=3.36e+09),
+    "c4": dict(profile="profiles/r2c_c4_rt_{stream,visibility}_kernel.txt", flops=6.4e+11, valu=1.79e+10, salu=7.68e+09, hbm_bytes=3.997e+09, rays=3.36e+09),
 }
 
 WORKLOADS = {
