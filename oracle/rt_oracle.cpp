@@ -108,11 +108,26 @@ inline bool intersect_sphere(V3<T> o, V3<T> d, V3<T> c, T radius, T* t_out, doub
 // reference returns t_max unchecked when t_min <= 0, :137 — a box wholly behind the origin yields t < 0,
 // which find_nearest_intersection's `if t and t < min_distance` (:162) ACCEPTS).
 template <typename T>
-inline bool intersect_cube(V3<T> o, V3<T> d, V3<T> lo, V3<T> hi, T* t_out) {
+inline bool intersect_cube(V3<T> o, V3<T> d, V3<T> lo, V3<T> hi, T* t_out, double* margin = nullptr) {
   T t_min = -std::numeric_limits<T>::infinity();          // :107
   T t_max = std::numeric_limits<T>::infinity();           // :108
   const T mins[3] = {lo.x, lo.y, lo.z}, maxs[3] = {hi.x, hi.y, hi.z};
   const T org[3] = {o.x, o.y, o.z}, dir[3] = {d.x, d.y, d.z};
+  if (margin) {   // diagnostic only (the sphere margin's counterpart): how close the slab intervals come to
+                  // "just touching" (a silhouette edge of the box), relative to the distances involved
+    double lo_all = -std::numeric_limits<double>::infinity(), hi_all = std::numeric_limits<double>::infinity();
+    for (int i = 0; i < 3; ++i) {
+      if (std::fabs(dir[i]) < T(1e-8)) continue;
+      double t1 = double((mins[i] - org[i]) / dir[i]), t2 = double((maxs[i] - org[i]) / dir[i]);
+      if (t1 > t2) { double tmp = t1; t1 = t2; t2 = tmp; }
+      if (t1 > lo_all) lo_all = t1;
+      if (t2 < hi_all) hi_all = t2;
+    }
+    if (std::isfinite(lo_all) && std::isfinite(hi_all)) {
+      double m = std::fabs(hi_all - lo_all) / std::fmax(1.0, std::fmax(std::fabs(lo_all), std::fabs(hi_all)));
+      if (m < *margin) *margin = m;
+    }
+  }
   for (int i = 0; i < 3; ++i) {                           // :110-122
     if (std::fabs(dir[i]) < T(1e-8)) {                    // :124
       if (org[i] < mins[i] || org[i] > maxs[i]) return false;   // :125-126
@@ -155,7 +170,8 @@ inline bool find_nearest(const SceneT<T>& s, V3<T> o, V3<T> d, Hit<T>* h, double
   for (int i = 0; i < s.n; ++i) {                         // :156
     T t;
     if (s.kind[i] == 1) {                                 // :159-160
-      if (!intersect_cube(o, d, s.center[i], s.box_max[i], &t)) continue;
+      if (!intersect_cube(o, d, s.center[i], s.box_max[i], &t, margin)) continue;
+      if (margin && t != T(0)) { if (t < min_distance) second = min_distance; else if (t < second) second = t; }
       if (t != T(0) && t < min_distance) {                // :162
         min_distance = t;
         V3<T> p = add(o, muls(d, t));                     // :168
@@ -176,7 +192,7 @@ inline bool find_nearest(const SceneT<T>& s, V3<T> o, V3<T> d, Hit<T>* h, double
     }
   }
   if (margin && found && std::isfinite(double(second))) {
-    double gap = (double(second) - double(min_distance)) / std::fmax(1e-30, double(min_distance));
+    double gap = (double(second) - double(min_distance)) / std::fmax(1e-30, std::fabs(double(min_distance)));
     if (gap < *margin) *margin = gap;
   }
   return found;
