@@ -10,8 +10,10 @@
 //   * the 13 shadow rays of one shading point are traced together (shared origin => shared
 //     `C - O`, sqrt-free any-hit test, sign-bit verdicts), and only against the few spheres that a
 //     per-object table (FP64, scene upload) and a per-point cone test leave as candidates;
-//   * sphere geometry is staged once per workgroup into LDS; up to 64 frames share one launch pair
-//     so that the persistent kernel's fixed cost is paid once.
+//   * sphere geometry is staged once per workgroup into LDS; up to RT_FRAMES_PER_LAUNCH (1024) frames share
+//     one launch pair so that the persistent kernel's fixed cost is paid once;
+//   * finished pixels leave as whole 8x8 tiles (per-wave tile slots in LDS), and up to 64 samples per pixel are
+//     shaded by one launch of the persistent kernel, summed per tile in LDS.
 // DESIGN.md describes the layout and the roofline; include/rt355.h documents the ABI.
 #include <hip/hip_runtime.h>
 
@@ -64,7 +66,8 @@ struct DevLights {
 };
 
 // frames per launch: the fixed cost of a launch pair (ramp-up, the stream kernel's uneven tail, the
-// gaps between dependent launches: ~0.1 ms) is paid once per batch — 16 -> 64 frames is +14 % on config 2
+// gaps between dependent launches: ~0.2 ms) is paid once per batch (measured on config 2 while the batch grew:
+// 16 -> 64 frames +12 %, 64 -> 256 +15 %, 256 -> 1024 +4 %)
 constexpr int kMaxBatch = RT_FRAMES_PER_LAUNCH;
 constexpr long long kRefrSumBytes = 32ll << 30;   // refractive scenes: most memory the float pixel sums of a launch may take
 struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
@@ -78,8 +81,8 @@ __device__ __forceinline__ int meta_level(uint32_t m) { return int(m & 127u); }
 __device__ __forceinline__ int meta_frame(uint32_t m) { return int((m >> 7) & 8191u); }
 __device__ __forceinline__ int meta_object(uint32_t m) { return int(m >> 20); }
 
-// Per-frame inputs of a batch.  A launch's kernel arguments are limited to 4 KB, so the cameras of up to
-// 256 frames live in device memory: rt_store_frames_kernel writes them there from kernel arguments,
+// Per-frame inputs of a batch.  A launch's kernel arguments are limited to 4 KB, so the cameras of a batch
+// (up to RT_FRAMES_PER_LAUNCH frames) live in device memory: rt_store_frames_kernel writes them there from kernel arguments,
 // 64 frames per (tiny) launch — no host-to-device copy, so the host never waits for the stream.
 struct __attribute__((aligned(64))) FrameRec {
   rt_camera cam;
