@@ -159,6 +159,9 @@ struct RenderParams {
 #define RT_VIS_WAVES 5     // its __launch_bounds__ occupancy target (waves per SIMD); 8 with 3+ tiles spills
 #endif
 constexpr int kVisTiles = RT_VIS_TILES;
+#ifndef RT_VIS_SKIP
+#define RT_VIS_SKIP 1      // the visibility pass culls per wave at any sphere count: blocks that no sphere reaches build no rays
+#endif
 #ifndef RT_VIS_CULL_FROM
 #define RT_VIS_CULL_FROM 16   // scenes with more spheres than this: the visibility pass culls per wave (primary_hit_culled)
 #endif
@@ -572,17 +575,24 @@ __device__ __forceinline__ void test_cam_group(const CamGroup& grp, int g, cgeom
     }
   if (int(any) >= 0) {
     // some lane may hit one of these four spheres: decide and measure with the cancellation-free
-    // form of nearest_hit (the table's c carries a safety margin, so this is a superset)
+    // form of nearest_hit (the table's c carries a safety margin, so this is a superset).  One wave-uniform
+    // branch and one scalar load per SPHERE that has a candidate in some lane and pixel (all four requested
+    // at once); its NP pixels are then tested without further branches — a branch, a load and a wait per
+    // (sphere, pixel) pair made blocks full of hits cost several times what their arithmetic does.
+    const float4 s4[4] = {geom[4 * g], geom[4 * g + 1], geom[4 * g + 2], geom[4 * g + 3]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      uint32_t cj = 0xFFFFFFFFu;
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        if (disc[q][j] >= 0.0f && nb[q][j] > 0.0f) {
+      for (int q = 0; q < NP; ++q) cj &= __float_as_uint(disc[q][j]) | __float_as_uint(nb[q][j]);
+      if (__ballot(int(cj) >= 0) != 0ull) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
           float dl;
-          const float t = sphere_t_exact(geom[4 * g + j], ox, oy, oz, dx[q], dy[q], dz[q], inv_a[q], dl);
+          const float t = sphere_t_exact(s4[j], ox, oy, oz, dx[q], dy[q], dz[q], inv_a[q], dl);
           // (`<` between spheres of one group and of groups in index order; the culled scan below may
           // visit groups in the same increasing order only, so ties still go to the lowest index)
-          if (dl >= 0.0f && t > 0.0f && t < best_t[q]) {
+          if (disc[q][j] >= 0.0f && nb[q][j] > 0.0f && dl >= 0.0f && t > 0.0f && t < best_t[q]) {
             best_t[q] = t;
             best_i[q] = 4 * g + j;
           }
@@ -628,9 +638,19 @@ struct RayCone {
 // of lighting()'s per-lane cull: the sphere reaches into the cone iff perp cos(t) - along sin(t) <= r,
 // with the same slack) — and only table groups that hold a surviving sphere are tested per ray.
 // ~25 VALU per 64 spheres instead of 16 NP per 4.  Groups are still visited in increasing order.
+// Does sphere s reach into the cone?  (the wave's cull: one sphere per lane)
+__device__ __forceinline__ bool sphere_in_cone(const float4 s, const RayCone& cone, float ox, float oy, float oz) {
+  const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+  const float d2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx)), r = fsqrt(s.w);
+  const float along = fmaf(cz, cone.az, fmaf(cy, cone.ay, cx * cone.ax));
+  const float perp2 = fmaxf(0.0f, fmaf(-along, along, d2));
+  const float rhs = fmaf(along, cone.sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
+  return rhs >= 0.0f && rhs * rhs >= perp2 * cone.cos2_t;
+}
+// (`first` = the ballot of sphere_in_cone over spheres 0..63, which the caller has taken already)
 template <int NP>
 __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
-                                                   int n, int lane, const RayCone& cone, float4 first_sphere,
+                                                   int n, int lane, const RayCone& cone, unsigned long long first,
                                                    float ox, float oy, float oz, const float (&dx)[NP],
                                                    const float (&dy)[NP], const float (&dz)[NP], float (&best_t)[NP],
                                                    int (&best_i)[NP]) {
@@ -644,15 +664,11 @@ __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg
   camtab_t tab = as_const(camtab);
   cgeom_t geom = as_const(gg);
   for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const float4 s = base == 0 ? first_sphere : gg[i < n ? i : n - 1];
-    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-    const float d2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx)), r = fsqrt(s.w);
-    const float along = fmaf(cz, cone.az, fmaf(cy, cone.ay, cx * cone.ax));
-    const float perp2 = fmaxf(0.0f, fmaf(-along, along, d2));
-    const float rhs = fmaf(along, cone.sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
-    const bool keep = i < n && rhs >= 0.0f && rhs * rhs >= perp2 * cone.cos2_t;
-    unsigned long long m = __ballot(keep);
+    unsigned long long m = first;
+    if (base != 0) {
+      const int i = base + lane;
+      m = __ballot(i < n && sphere_in_cone(gg[i < n ? i : n - 1], cone, ox, oy, oz));
+    }
     m |= m >> 1; m |= m >> 2;
     m &= 0x1111111111111111ull;              // bit 4 k: group k of this chunk holds a sphere to test
     while (m != 0ull) {
@@ -1236,15 +1252,68 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   uint32_t rgbx[NT];                                      // hit pixels: placeholder
 #pragma unroll
   for (int q = 0; q < NT; ++q) { idx[q] = -1; rgbx[q] = 0u; }
-  // many spheres: the wave culls them against the bounding cone of its rays (primary_hit_culled); the
-  // first 64 spheres are requested now, so the load is covered by the ray set-up
-  const bool cull = p.n_spheres > kVisCullFrom;
+  // The wave culls the spheres against the bounding cone of its rays first (primary_hit_culled): with many
+  // spheres only the table groups that hold a survivor are tested per ray, and with ANY number of spheres a
+  // block that no sphere reaches (sky: 81 % of config 2's tiles) builds no rays at all.  The first 64 spheres
+  // are requested now, so the load is covered by the cone's arithmetic.
+  const bool cull = RT_VIS_SKIP ? p.n_spheres > 0 : p.n_spheres > kVisCullFrom;
   float4 first_sphere = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cull) first_sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
   if (live[0] || cull) {                                  // (a later tile's pixel is live only if the first one's is;
     const FrameRec fr = as_const(p.frames)[frame];        //  with the cull all lanes take part in its ballots)
     const rt_camera& cam = fr.cam;
     const int y = tile_rows_uniform(p) ? tile_row_base(p, row0) + ly : row_of(p, row0 + ly);
+    const CamGroup* table = p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres);
+    RayCone cone{0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned long long first = 0ull;                      // spheres 0..63 that reach into the block's cone
+    if (cull) {
+      // the block's rays: pixel x + r, y + r with r in [0, 1) -> u in [u0, u1], v in [v1, v0] (render_pixel
+      // :293-294); their directions right u + up v + forward form a planar patch, so the largest angle
+      // to the centre direction is at a corner.  Lanes 0..3 take a corner each, the others the centre.
+      const int ya = tile_rows_uniform(p) ? tile_row_base(p, row0) : row_of(p, row0);
+      const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
+      const float u0 = float(p.x0 + col0) * p.inv_w * 2.0f - 1.0f, u1 = float(p.x0 + col0 + 8 * NT) * p.inv_w * 2.0f - 1.0f;
+      const float v0 = -(float(ya) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect, v1 = -(float(yb) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect;
+      const float ul = lane < 4 ? ((lane & 1) ? u1 : u0) : 0.5f * (u0 + u1);
+      const float vl = lane < 4 ? ((lane & 2) ? v1 : v0) : 0.5f * (v0 + v1);
+      float ex = fmaf(cam.up[0], vl, cam.right[0] * ul) + cam.forward[0];
+      float ey = fmaf(cam.up[1], vl, cam.right[1] * ul) + cam.forward[1];
+      float ez = fmaf(cam.up[2], vl, cam.right[2] * ul) + cam.forward[2];
+      const float einv = frsq(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+      ex *= einv; ey *= einv; ez *= einv;
+      auto from_lane = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+      cone.ax = from_lane(ex, 4); cone.ay = from_lane(ey, 4); cone.az = from_lane(ez, 4);
+      const float cl = fmaf(ez, cone.az, fmaf(ey, cone.ay, ex * cone.ax));   // corners: cos of the angle to the axis
+      float cmin = fminf(fminf(from_lane(cl, 0), from_lane(cl, 1)), fminf(from_lane(cl, 2), from_lane(cl, 3)));
+      cmin = fmaxf(0.0f, fminf(1.0f, cmin) - 1e-5f);      // FP32 error of the above is ~1e-7
+      cone.cos2_t = cmin * cmin;
+      cone.sin_t = fsqrt(fmaxf(0.0f, 1.0f - cone.cos2_t));
+      first = __ballot(lane < p.n_spheres && sphere_in_cone(first_sphere, cone, cam.origin[0], cam.origin[1], cam.origin[2]));
+    }
+    // a block that no sphere reaches builds no rays: all its pixels miss (with more than 64 spheres the later
+    // chunks are not looked at here, and with cubes every ray is needed for them)
+    #if defined(RT_EXP_VIS_NORAYS)
+    const bool need_rays = false;   // timing experiment only: the pass's floor (cone, cull, black pixels)
+#else
+    const bool need_rays = !RT_VIS_SKIP || CUBES || first != 0ull || p.n_spheres > 64;
+#endif
+    if constexpr (!MULTI) {
+      // The common case of such a block — whole, one sample per pixel, 8-bit frame only, dword-aligned rows —
+      // leaves at once: its rows are NT x 24 contiguous bytes of black, 12 per lane with NT = 4 (one store
+      // instruction for the wave), and nothing else is owed (no record, no occupancy bit).
+      if (!need_rays && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && rows == 8 &&
+          cols[NT - 1] == 8 && (p.nx & 3) == 0 && (frame_px & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0) {
+        uint8_t* o = p.out_rgb + (frame_px + (long long)(row0 + ly) * p.nx + col0) * 3;
+        if constexpr (NT == 4) {
+          uint32_t* w = reinterpret_cast<uint32_t*>(o + lx * 12);
+          w[0] = 0u; w[1] = 0u; w[2] = 0u;
+        } else {
+          for (int i = lx; i < 6 * NT; i += 8) reinterpret_cast<uint32_t*>(o)[i] = 0u;
+        }
+        return;
+      }
+    }
+    if (need_rays) {
     float dx[NT], dy[NT], dz[NT], t[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
@@ -1252,40 +1321,11 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
       primary_ray<MODE>(p, cam, fr.seed, p.x0 + col0 + 8 * q + lx, y, p.sample_index, pixel_key, dx[q], dy[q],
                         dz[q]);
     }
-    const CamGroup* table = p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres);
-    if (cull) {
-      // the block's rays: pixel x + r, y + r with r in [0, 1) -> u in [u0, u1], v in [v1, v0] (render_pixel
-      // :293-294); their directions right u + up v + forward form a planar patch, so the largest angle
-      // to the centre direction is at a corner
-      const int ya = tile_rows_uniform(p) ? tile_row_base(p, row0) : row_of(p, row0);
-      const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
-      const float u0 = float(p.x0 + col0) * p.inv_w * 2.0f - 1.0f, u1 = float(p.x0 + col0 + 8 * NT) * p.inv_w * 2.0f - 1.0f;
-      const float v0 = -(float(ya) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect, v1 = -(float(yb) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect;
-      const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1);
-      auto dir = [&](float u, float v, float& x, float& yy, float& z) {
-        x = fmaf(cam.up[0], v, cam.right[0] * u) + cam.forward[0];
-        yy = fmaf(cam.up[1], v, cam.right[1] * u) + cam.forward[1];
-        z = fmaf(cam.up[2], v, cam.right[2] * u) + cam.forward[2];
-        const float inv = frsq(fmaf(z, z, fmaf(yy, yy, x * x)));
-        x *= inv; yy *= inv; z *= inv;
-      };
-      RayCone cone;
-      dir(uc, vc, cone.ax, cone.ay, cone.az);
-      float cmin = 1.0f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float x, yy, z;
-        dir(k & 1 ? u1 : u0, k & 2 ? v1 : v0, x, yy, z);
-        cmin = fminf(cmin, fmaf(z, cone.az, fmaf(yy, cone.ay, x * cone.ax)));
-      }
-      cmin = fmaxf(0.0f, cmin - 1e-5f);                   // FP32 error of the above is ~1e-7
-      cone.cos2_t = cmin * cmin;
-      cone.sin_t = fsqrt(fmaxf(0.0f, 1.0f - cone.cos2_t));
-      primary_hit_culled<NT>(p.geom, table, p.n_spheres, lane, cone, first_sphere, cam.origin[0], cam.origin[1],
+    if (p.n_spheres > kVisCullFrom)
+      primary_hit_culled<NT>(p.geom, table, p.n_spheres, lane, cone, first, cam.origin[0], cam.origin[1],
                              cam.origin[2], dx, dy, dz, t, idx);
-    } else {
+    else   // few spheres: every group is scanned (pipelined scalar loads: cheaper here than group-by-group fetches)
       primary_hit_n<NT>(p.geom, table, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
-    }
     if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
       cgeom_t cg = as_const(p.cubes);
       float ix[NT], iy[NT], iz[NT];
@@ -1304,6 +1344,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
         }
       }
     }
+    }   // need_rays
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       if (!live[q]) idx[q] = -1;
