@@ -1252,6 +1252,12 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   uint32_t rgbx[NT];                                      // hit pixels: placeholder
 #pragma unroll
   for (int q = 0; q < NT; ++q) { idx[q] = -1; rgbx[q] = 0u; }
+  // The common case: a whole block of an 8-bit frame with dword-aligned rows, one sample per pixel, nothing else
+  // asked for.  Every pixel this kernel writes is then black (misses are final, hits get a placeholder), which
+  // the short forms of the epilogue below rely on.
+  const bool simple = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && rows == 8 &&
+                      cols[NT - 1] == 8 && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
   // The wave culls the spheres against the bounding cone of its rays first (primary_hit_culled): with many
   // spheres only the table groups that hold a survivor are tested per ray, and with ANY number of spheres a
   // block that no sphere reaches (sky: 81 % of config 2's tiles) builds no rays at all.  The first 64 spheres
@@ -1301,8 +1307,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
       // The common case of such a block — whole, one sample per pixel, 8-bit frame only, dword-aligned rows —
       // leaves at once: its rows are NT x 24 contiguous bytes of black, 12 per lane with NT = 4 (one store
       // instruction for the wave), and nothing else is owed (no record, no occupancy bit).
-      if (!need_rays && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && rows == 8 &&
-          cols[NT - 1] == 8 && (p.nx & 3) == 0 && (frame_px & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0) {
+      if (!need_rays && simple) {
         uint8_t* o = p.out_rgb + (frame_px + (long long)(row0 + ly) * p.nx + col0) * 3;
         if constexpr (NT == 4) {
           uint32_t* w = reinterpret_cast<uint32_t*>(o + lx * 12);
@@ -1345,6 +1350,33 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
       }
     }
     }   // need_rays
+    if constexpr (!MULTI) {
+      if (simple) {
+        // hand-over (see below) and black pixels of a whole block: a tile with a hit gets its record, header and
+        // occupancy bit; a tile the stream kernel will not store gets 8 x 24 bytes of black, 48 lanes x one dword
+        int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tile_pitch + (col0 >> 3)) * kVisTile;
+        const uint32_t id0 = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
+                             uint32_t(col0 >> 3);
+        const int r = (lane * 43) >> 8, w = lane - 6 * r;          // lane l < 48: dword w of tile row r
+        uint8_t* o = p.out_rgb + (frame_px + (long long)(row0 + r) * p.nx + col0) * 3 + w * 4;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const bool occupied = __ballot(idx[q] >= 0) != 0ull;
+          if (occupied) {
+            rec[q * kVisTile + lane] = int16_t(idx[q]);
+            if (lane == 0) {
+              *reinterpret_cast<uint2*>(rec + q * kVisTile + 64) =
+                  make_uint2(uint32_t((col0 >> 3) + q) | (uint32_t(row0 >> 3) << 16), uint32_t(frame));
+              const uint32_t id = id0 + uint32_t(q);
+              const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
+              atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));
+            }
+          }
+          if (!(occupied && p.tile_flush) && lane < 48) *reinterpret_cast<uint32_t*>(o + q * 24) = 0u;
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       if (!live[q]) idx[q] = -1;
