@@ -1303,6 +1303,9 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
 #else
     const bool need_rays = !RT_VIS_SKIP || CUBES || first != 0ull || p.n_spheres > 64;
 #endif
+    // (nothing to write at all: a sample before the last of the MULTI path leaves only records and `present` bits
+    // of tiles it hit; on the deferred-output path — refractive scenes — every pixel comes from rt_resolve_kernel)
+    if (!need_rays && !p.out_hit && (MULTI ? !last_sample : p.defer_output != 0)) return;
     if constexpr (!MULTI) {
       // The common case of such a block — whole, one sample per pixel, 8-bit frame only, dword-aligned rows —
       // leaves at once: its rows are NT x 24 contiguous bytes of black, 12 per lane with NT = 4 (one store
