@@ -1228,13 +1228,38 @@ __device__ __forceinline__ void store_tile8(uint8_t* __restrict__ out, int nx, i
 // profiles/r1_ubench_issue_mix.txt), so it has no LDS staging, no barrier and no per-lane divisions:
 // the packed RGB rows of a tile (24 B each) are assembled across lanes with ds_bpermute.
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool CUBES, bool MULTI = false>
-__global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
-  // a wave covers kVisTiles 8x8 tiles side by side: lane (lx, ly) traces pixel (lx, ly) of each
+// Bounding cone of the primary rays of window columns [xa, xb) x image rows [ya, yb): pixel x + r, y + r with r in
+// [0, 1) -> u in [u0, u1], v in [v1, v0] (render_pixel :293-294); the directions right u + up v + forward form a
+// planar patch, so the largest angle to the centre direction is at a corner.  Lanes 0..3 take a corner each, the
+// others the centre.
+__device__ __forceinline__ RayCone bundle_cone(const RenderParams& p, const rt_camera& cam, int lane, int xa, int xb,
+                                               int ya, int yb) {
+  const float u0 = float(xa) * p.inv_w * 2.0f - 1.0f, u1 = float(xb) * p.inv_w * 2.0f - 1.0f;
+  const float v0 = -(float(ya) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect, v1 = -(float(yb) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect;
+  const float ul = lane < 4 ? ((lane & 1) ? u1 : u0) : 0.5f * (u0 + u1);
+  const float vl = lane < 4 ? ((lane & 2) ? v1 : v0) : 0.5f * (v0 + v1);
+  float ex = fmaf(cam.up[0], vl, cam.right[0] * ul) + cam.forward[0];
+  float ey = fmaf(cam.up[1], vl, cam.right[1] * ul) + cam.forward[1];
+  float ez = fmaf(cam.up[2], vl, cam.right[2] * ul) + cam.forward[2];
+  const float einv = frsq(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+  ex *= einv; ey *= einv; ez *= einv;
+  auto from_lane = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  RayCone cone;
+  cone.ax = from_lane(ex, 4); cone.ay = from_lane(ey, 4); cone.az = from_lane(ez, 4);
+  const float cl = fmaf(ez, cone.az, fmaf(ey, cone.ay, ex * cone.ax));   // corners: cos of the angle to the axis
+  float cmin = fminf(fminf(from_lane(cl, 0), from_lane(cl, 1)), fminf(from_lane(cl, 2), from_lane(cl, 3)));
+  cmin = fmaxf(0.0f, fminf(1.0f, cmin) - 1e-5f);      // FP32 error of the above is ~1e-7
+  cone.cos2_t = cmin * cmin;
+  cone.sin_t = fsqrt(fmaxf(0.0f, 1.0f - cone.cos2_t));
+  return cone;
+}
+
+// One block of the visibility pass: kVisTiles 8x8 tiles side by side, rows row0 .. row0 + 7 of the window, one wave.
+template <int MODE, bool CUBES, bool MULTI>
+__device__ __forceinline__ void visibility_block(const RenderParams& p, const int frame, const int row0, const int col0,
+                                                 const int lane) {
+  // lane (lx, ly) traces pixel (lx, ly) of each tile
   constexpr int NT = kVisTiles;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), row0 = int(blockIdx.x) * 8;   // window coordinates
   const int lx = lane & 7, ly = lane >> 3;
   const int rows = min(8, p.n_rows - row0);
   int cols[NT];
@@ -1273,27 +1298,9 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     RayCone cone{0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned long long first = 0ull;                      // spheres 0..63 that reach into the block's cone
     if (cull) {
-      // the block's rays: pixel x + r, y + r with r in [0, 1) -> u in [u0, u1], v in [v1, v0] (render_pixel
-      // :293-294); their directions right u + up v + forward form a planar patch, so the largest angle
-      // to the centre direction is at a corner.  Lanes 0..3 take a corner each, the others the centre.
       const int ya = tile_rows_uniform(p) ? tile_row_base(p, row0) : row_of(p, row0);
       const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
-      const float u0 = float(p.x0 + col0) * p.inv_w * 2.0f - 1.0f, u1 = float(p.x0 + col0 + 8 * NT) * p.inv_w * 2.0f - 1.0f;
-      const float v0 = -(float(ya) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect, v1 = -(float(yb) * p.inv_h * 2.0f - 1.0f) * p.inv_aspect;
-      const float ul = lane < 4 ? ((lane & 1) ? u1 : u0) : 0.5f * (u0 + u1);
-      const float vl = lane < 4 ? ((lane & 2) ? v1 : v0) : 0.5f * (v0 + v1);
-      float ex = fmaf(cam.up[0], vl, cam.right[0] * ul) + cam.forward[0];
-      float ey = fmaf(cam.up[1], vl, cam.right[1] * ul) + cam.forward[1];
-      float ez = fmaf(cam.up[2], vl, cam.right[2] * ul) + cam.forward[2];
-      const float einv = frsq(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
-      ex *= einv; ey *= einv; ez *= einv;
-      auto from_lane = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-      cone.ax = from_lane(ex, 4); cone.ay = from_lane(ey, 4); cone.az = from_lane(ez, 4);
-      const float cl = fmaf(ez, cone.az, fmaf(ey, cone.ay, ex * cone.ax));   // corners: cos of the angle to the axis
-      float cmin = fminf(fminf(from_lane(cl, 0), from_lane(cl, 1)), fminf(from_lane(cl, 2), from_lane(cl, 3)));
-      cmin = fmaxf(0.0f, fminf(1.0f, cmin) - 1e-5f);      // FP32 error of the above is ~1e-7
-      cone.cos2_t = cmin * cmin;
-      cone.sin_t = fsqrt(fmaxf(0.0f, 1.0f - cone.cos2_t));
+      cone = bundle_cone(p, cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
       first = __ballot(lane < p.n_spheres && sphere_in_cone(first_sphere, cone, cam.origin[0], cam.origin[1], cam.origin[2]));
     }
     // a block that no sphere reaches builds no rays: all its pixels miss (with more than 64 spheres the later
@@ -1446,6 +1453,70 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     // (tile_flush: the stream kernel stores an occupied tile whole, its black pixels included)
     if (write_rgb && !(occupied && p.tile_flush))
       store_tile8(out, p.nx, row0, col0 + 8 * q, rows, cols[q], lane, rgbx[q], dwords);
+  }
+}
+
+
+// The kernel: a workgroup is 4 waves side by side; a wave takes kVisRows blocks one below the other — a region of
+// 32 x 32 pixels with the defaults.  Before anything else the wave culls the scene against the cone of the WHOLE
+// region: most regions of a mostly-sky frame hold nothing, and such a region of a plain 8-bit frame leaves as 32
+// rows of black from one cone and one cull turn (a quarter of what its four blocks would spend to find out the same).
+#ifndef RT_VIS_ROWS
+#define RT_VIS_ROWS 4
+#endif
+constexpr int kVisRows = RT_VIS_ROWS;
+template <int MODE, bool CUBES, bool MULTI = false>
+__global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
+  constexpr int NT = kVisTiles;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.z;
+  const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * kVisRows);   // window coordinates
+  if (p.nx - col0 <= 0) return;                           // wave-uniform: beyond the right edge
+  if constexpr (RT_VIS_SKIP && !CUBES && kVisRows > 1) {
+    const long long frame_px = (long long)frame * p.frame_stride_px;
+    const bool whole = rowR + 8 * kVisRows <= p.n_rows && p.nx - col0 >= 8 * NT;
+    const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : p.defer_output != 0);
+    const bool black_owed = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && whole &&
+                            (p.nx & 3) == 0 && (frame_px & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
+    if ((nothing_owed || black_owed) && p.n_spheres <= 64) {
+      bool any = false;
+      if (p.n_spheres > 0) {
+        const float4 sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
+        const FrameRec fr = as_const(p.frames)[frame];
+        const int last = min(rowR + 8 * kVisRows, p.n_rows) - 1;
+        const int ya = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + rowR : row_of(p, rowR);
+        const int yb = (p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + last : row_of(p, last)) + 1;
+        const RayCone cone = bundle_cone(p, fr.cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
+        any = __ballot(lane < p.n_spheres && sphere_in_cone(sphere, cone, fr.cam.origin[0], fr.cam.origin[1], fr.cam.origin[2])) != 0ull;
+      }
+      if (!any) {
+        if (black_owed) {
+          const int lx = lane & 7, ly = lane >> 3;
+          uint8_t* o = p.out_rgb + (frame_px + (long long)(rowR + ly) * p.nx + col0) * 3;
+#pragma unroll
+          for (int b = 0; b < kVisRows; ++b) {
+            uint8_t* ob = o + (long long)(8 * b) * p.nx * 3;
+            if constexpr (NT == 4) {
+              uint32_t* w = reinterpret_cast<uint32_t*>(ob + lx * 12);
+              w[0] = 0u; w[1] = 0u; w[2] = 0u;
+            } else {
+              for (int i = lx; i < 6 * NT; i += 8) reinterpret_cast<uint32_t*>(ob)[i] = 0u;
+            }
+          }
+        }
+        return;
+      }
+    }
+  }
+#pragma nounroll
+  for (int b = 0; b < kVisRows; ++b) {
+    const int row0 = rowR + 8 * b;
+    if (row0 >= p.n_rows) break;
+    // (the argument block is read afresh per block, as in the stream kernel: hoisted out of this loop its fields
+    // and everything derived from them would not fit the scalar registers)
+    int lane_b = int(threadIdx.x) & 63;
+    asm volatile("" : "+v"(lane_b));
+    visibility_block<MODE, CUBES, MULTI>(params_here(), frame, row0, col0, lane_b);
   }
 }
 
@@ -3018,7 +3089,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       p.sample_index = s;
       if (stream_kernel) {
         // one wave per pair of 8x8 tiles, 8 tiles (64 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
-        const dim3 vgrid(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf));
+        const dim3 vgrid(unsigned((w.n_rows + 8 * kVisRows - 1) / (8 * kVisRows)), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf));
         const size_t vlds = 0;
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
