@@ -103,12 +103,17 @@ int rt_synchronize(rt_ctx* ctx);
  *   tile whole (8 x 24 contiguous bytes, whole dwords) when its last pixel is in — the coalesced packed-RGB store
  *   of the frame (raytracer.py:318, :325); 0 = every finished pixel is stored by itself (three byte stores: one
  *   memory request per pixel).  Same bytes either way (tests).  Used for 8-bit frames at one sample per pixel of
- *   scenes without refraction; the other paths store as before. */
+ *   scenes without refraction; the other paths store as before.
+ *   RT_OPT_REFLECT_TABLE: 1 (default) = reflection rays of sphere-only opaque scenes with 4 .. 255 spheres look
+ *   only at the spheres a table built at scene upload lists for (object they leave, direction bucket) — see
+ *   rt_reflect_table; 0 = the plain scan of find_nearest_intersection (raytracer.py:152-172).  Same images
+ *   (tests); takes effect at the next rt_upload_scene. */
 #define RT_OPT_KERNEL 1
 #define RT_OPT_OCCLUDER_TABLE 2
 #define RT_OPT_SPHERE_GRID 3
 #define RT_OPT_QUEUE_SPILL 4
 #define RT_OPT_TILE_FLUSH 5
+#define RT_OPT_REFLECT_TABLE 6
 #define RT_KERNEL_STREAM 0
 #define RT_KERNEL_PIXEL 1
 int rt_set_option(rt_ctx* ctx, int option, int value);
@@ -137,6 +142,17 @@ int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refract
  * superset property can be tested against brute force without a GPU.
  * out_words: n * ceil(n/32) uint32. */
 int rt_occluder_table(const float* geom4, int n_spheres, const rt_lights* lights, uint32_t* out_words);
+
+/* Host-only helper (needs no GPU, no context): the direction table rt_upload_scene builds for the reflection rays
+ * of find_nearest_intersection (raytracer.py:152-172, called from trace_ray :246-248).  Directions are bucketed on
+ * a cube map: face 2 m + (d[m] < 0) for the major axis m, cell (ix, iy) = floor((d[(m+1)%3] / |d[m]| + 1) dim / 2),
+ * floor((d[(m+2)%3] / |d[m]| + 1) dim / 2), bucket = (face * dim + iy) * dim + ix.  Entry [k][bucket] is
+ * ceil(n/64) pairs of uint32 (bits 0..31, 32..63 of each 64 spheres); bit j set = some ray that starts within
+ * 0.001 of sphere k's surface with a direction in the bucket can hit sphere j (j != k) — a conservative superset
+ * computed in FP64; the kernels test only those spheres (and test them exactly).  No counterpart in the reference
+ * (which tests every sphere); exported so that the superset property can be tested against brute force without a
+ * GPU.  out_words: n * 6 dim^2 * 2 ceil(n/64) uint32; 1 <= dim <= 16. */
+int rt_reflect_table(const float* geom4, int n_spheres, int dim, uint32_t* out_words);
 
 /* Cube objects (raytracer.py:56-60) in the list find_nearest_intersection scans (:156-160, :164-169):
  * intersect_cube (:106-137) and cube_normal (:142-150).  n_cubes boxes, host pointers:

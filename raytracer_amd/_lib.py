@@ -19,12 +19,13 @@ RT_OPT_OCCLUDER_TABLE = 2
 RT_OPT_SPHERE_GRID = 3
 RT_OPT_QUEUE_SPILL = 4
 RT_OPT_TILE_FLUSH = 5
+RT_OPT_REFLECT_TABLE = 6
 RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT: RT_RNG_CONSTANT,
              "K": RT_RNG_KEYED, "keyed": RT_RNG_KEYED}
 
 #: every symbol include/rt355.h declares (tests check the .so exports all of them)
 SYMBOLS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize",
-           "rt_set_option", "rt_upload_scene", "rt_set_refraction", "rt_set_cubes", "rt_occluder_table", "rt_render", "rt_render_noalloc", "rt_render_rows", "rt_render_frames_rows",
+           "rt_set_option", "rt_upload_scene", "rt_set_refraction", "rt_set_cubes", "rt_occluder_table", "rt_reflect_table", "rt_render", "rt_render_noalloc", "rt_render_rows", "rt_render_frames_rows",
            "rt_render_chunk", "rt_render_frames",
            "rt_scatter_rows", "rt_scatter_rows_frames", "rt_compact_tiles", "rt_place_tiles", "rt_get_ray_counts", "rt_reset_ray_counts", "rt_debug_counters", "rt_version")
 
@@ -62,6 +63,7 @@ def load():
     L.rt_upload_scene.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, P(RtLights)]
     L.rt_set_refraction.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.rt_occluder_table.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+    L.rt_reflect_table.argtypes = [c_void_p, c_int, c_int, c_void_p]
     L.rt_set_cubes.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]
     L.rt_render.argtypes = [c_void_p, P(RtCamera), c_int, c_int, c_int, c_int, c_int, c_u64,
                             c_void_p, c_void_p]

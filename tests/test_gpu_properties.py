@@ -277,6 +277,38 @@ def test_sphere_grid_changes_no_byte(renderer):
         renderer.set_sphere_grid(True)
 
 
+def test_reflect_table_changes_no_byte(renderer):
+    """Reflection rays through the per-object direction table (sphere-only opaque scenes with 4..255 spheres) find
+    the same hits as the plain scan: byte-identical frames and hit maps with RT_OPT_REFLECT_TABLE on and off, depth
+    up to 8, other cameras, tables of every bucket count (16 / 8 / 4 per face edge, chosen by size), spheres that
+    nearly touch, and a scene with a huge floor sphere that the others rest on."""
+    import torch
+    from raytracer_amd.scenes import Material, Sphere, Vector3
+    floor = generate_scene(40, 11)
+    floor["spheres"].append(Sphere(Vector3(0, -1003, -12), 1000, Material(Vector3(0.8, 0.8, 0.8), specular=0.3, reflection=0.5)))
+    pair = generate_scene(20, 13)
+    pair["spheres"].append(Sphere(Vector3(-0.6, 0.2, -4), 0.6, Material(Vector3(0.9, 0.3, 0.3), specular=1.0, reflection=0.7)))
+    pair["spheres"].append(Sphere(Vector3(0.6005, 0.2, -4), 0.6, Material(Vector3(0.3, 0.3, 0.9), specular=1.0, reflection=0.7)))
+    cases = [(generate_scene(8, 1, keep_default=True), 640, 360, 5), (generate_scene(16, 4), 640, 360, 5), (generate_scene(64, 2), 960, 540, 8), (generate_scene(100, 5), 640, 360, 5),
+             (generate_scene(255, 6), 640, 360, 6), (floor, 640, 360, 6), (pair, 640, 360, 8)]
+    try:
+        for scene, w, h, D in cases:
+            out = []
+            for on in (True, False):
+                renderer.set_reflect_table(on)
+                renderer.upload_scene(scene)
+                renderer.reset_ray_counts()
+                frames = [renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=3, camera=cam, return_hit_index=True)
+                          for cam in (None, orbit_camera(37, 256), orbit_camera(150, 256, radius=14.0))]
+                out.append((frames, renderer.ray_counts()))
+            (fa, ca), (fb, cb) = out
+            assert ca == cb and ca["reflection"] > 0
+            for (a, ha), (b, hb) in zip(fa, fb):
+                assert torch.equal(a, b) and torch.equal(ha, hb)
+    finally:
+        renderer.set_reflect_table(True)
+
+
 def test_queue_spill_changes_only_summation_order(renderer):
     """Refractive scenes: a wave whose work queue is full sets records aside in device memory
     (RT_OPT_QUEUE_SPILL, default) or only shrinks its passes.  Same tree nodes either way: identical ray counts and

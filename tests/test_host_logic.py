@@ -184,6 +184,58 @@ def test_occluder_table_is_a_superset_of_brute_force():
             assert bits.sum(1).mean() < 0.25 * n
 
 
+def test_reflect_table_is_a_superset_of_brute_force():
+    """rt_reflect_table (host-only, FP64): bit j of entry [k][bucket] must be set for every ray that leaves sphere k
+    (random surface points, offset 0.001 along the normal, raytracer.py:247; random outward directions — every
+    reflected direction is one) with a direction in the bucket and hits sphere j (intersect_sphere :93-104).  The
+    bucket of a direction is computed here in FP32, as the kernel does it."""
+    import ctypes
+    from raytracer_amd import _lib
+    from raytracer_amd.scenes import generate_scene, pack_scene
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    for scene, B in ((generate_scene(16, 9), 16), (generate_scene(64, 2), 16), (generate_scene(64, 2), 4), (generate_scene(150, 7), 8)):
+        p = pack_scene(scene)
+        n, pairs, nb = p.n_spheres, (p.n_spheres + 63) // 64, 6 * B * B
+        out = np.zeros((n, nb, pairs * 2), np.uint32)
+        g = np.ascontiguousarray(p.geom4, np.float32)
+        assert L.rt_reflect_table(g.ctypes.data, n, B, out.ctypes.data) == 0
+        bits = ((out[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, nb, -1)[:, :, :n].astype(bool)
+        assert not bits[np.arange(n), :, np.arange(n)].any()           # an object never lists itself
+        C = p.geom4[:, :3].astype(np.float64); r = np.sqrt(p.geom4[:, 3].astype(np.float64))
+        missing = 0
+        for k in range(n):
+            m = 3000
+            nrm = rng.normal(size=(m, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            O = C[k] + nrm * (r[k] + 0.001)
+            D = rng.normal(size=(m, 3)); D /= np.linalg.norm(D, axis=1, keepdims=True)
+            D = np.where((np.sum(D * nrm, 1) < 0)[:, None], -D, D)    # outward, like a reflected ray
+            # aim half of the rays at other spheres (random points in them), so that hits are not rare
+            tgt = rng.integers(0, n, m); aim = C[tgt] + rng.normal(size=(m, 3)) * (r[tgt][:, None] * 0.6)
+            Da = aim - O; Da /= np.linalg.norm(Da, axis=1, keepdims=True)
+            use = (rng.random(m) < 0.5) & (tgt != k) & (np.sum(Da * nrm, 1) > 0)
+            D = np.where(use[:, None], Da, D)
+            Df = D.astype(np.float32)
+            a = np.abs(Df); mx = (a[:, 0] >= a[:, 1]) & (a[:, 0] >= a[:, 2]); my = ~mx & (a[:, 1] >= a[:, 2])
+            mi = np.where(mx, 0, np.where(my, 1, 2)); idx = np.arange(m)
+            major = Df[idx, mi]; inv = np.float32(1.0) / np.abs(major)
+            hB = np.float32(0.5 * B)
+            ix = np.clip((Df[idx, (mi + 1) % 3] * inv * hB + hB).astype(np.int32), 0, B - 1)
+            iy = np.clip((Df[idx, (mi + 2) % 3] * inv * hB + hB).astype(np.int32), 0, B - 1)
+            bucket = ((2 * mi + (major < 0)) * B + iy) * B + ix
+            oc = O[:, None, :] - C[None, :, :]
+            b = 2 * np.einsum("psk,pk->ps", oc, D)
+            c = np.einsum("psk,psk->ps", oc, oc) - r[None, :] ** 2
+            disc = b * b - 4 * c
+            tt = (-b - np.sqrt(np.maximum(disc, 0))) / 2
+            hit = (disc >= 0) & (tt > 0)
+            hit[:, k] = False
+            missing += int((hit & ~bits[k, bucket]).sum())
+        assert missing == 0, "a sphere that a ray hits is missing from its bucket"
+        if B >= 8:       # and the table is selective: a few spheres per bucket, not all of them
+            assert bits.sum(2).mean() < 0.1 * n
+
+
 def test_pack_scene_enforces_the_cube_limit_before_the_device_is_touched():
     """rt_set_cubes accepts n_spheres + 2 n_cubes <= RT_MAX_SPHERES; pack_scene raises for anything beyond, so
     Renderer.upload_scene cannot fail between rt_upload_scene and rt_set_cubes on a scene that is merely too large."""
