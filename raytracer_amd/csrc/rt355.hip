@@ -2195,7 +2195,8 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
             float t;
             int idx2, face;
             ++n_trace;
-            nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
+            if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), sx, sy, sz, rdx, rdy, rdz, t, idx2); face = 0; }
+            else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
             if (idx2 >= 0) {
               push_r = true;
               hit_point<CUBES>(sg, p.n_spheres, idx2, face, sx, sy, sz, rdx, rdy, rdz, t, rpx, rpy, rpz);
@@ -2223,7 +2224,9 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
               float t;
               int idx2, face;
               ++n_trace;
-              nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
+              // (the refracted ray starts 0.001 INSIDE the object: still within reach of the table's bound)
+              if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), ox, oy, oz, fdx, fdy, fdz, t, idx2); face = 0; }
+              else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
               if (idx2 >= 0) {
                 push_f = true;
                 hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, fdx, fdy, fdz, t, fpx, fpy, fpz);
@@ -3096,7 +3099,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.grid_start = ctx->d_grid_start; p.grid_items = ctx->d_grid_items; p.grid_big = ctx->d_grid_big;
   p.grid_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->grid_dim;
   p.refl_tab = ctx->d_refl_tab; p.refl_pairs = ctx->refl_pairs;
-  p.refl_dim = (refr || cubes || !stream_kernel || p.grid_dim > 0) ? 0 : ctx->refl_dim;
+  p.refl_dim = (cubes || !stream_kernel || p.grid_dim > 0) ? 0 : ctx->refl_dim;
   p.grid_n_big = ctx->grid_n_big;
   for (int k = 0; k < 3; ++k) {
     p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];

@@ -309,6 +309,35 @@ def test_reflect_table_changes_no_byte(renderer):
         renderer.set_reflect_table(True)
 
 
+def test_reflect_table_on_refractive_scenes(renderer):
+    """Refractive scenes send their reflected AND refracted rays (origins 0.001 outside / inside the object) through
+    the same direction table.  Pixel sums are float atomics there, so frames agree up to summation order; the tree is
+    the same: identical ray counts and hit maps.  The glass-sphere scene, and 40 generated spheres every third of
+    glass (some of them seen through others), depth 5 and 8."""
+    import torch
+    from raytracer_amd.scenes import refractive_scene
+    many = generate_scene(40, 12)
+    for i, s_ in enumerate(many["spheres"]):
+        if i % 3 == 0:
+            s_.material.refraction, s_.material.refractive_index = 0.6, 1.4
+    cases = [(refractive_scene(), 640, 360, 5), (many, 640, 360, 5), (many, 480, 270, 8)]
+    try:
+        for scene, w, h, D in cases:
+            out = []
+            for on in (False, True):
+                renderer.set_reflect_table(on)
+                renderer.upload_scene(scene)
+                renderer.reset_ray_counts()
+                img, hit = renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=5, return_hit_index=True)
+                out.append((img.to(torch.int16), hit, renderer.ray_counts()))
+            (a, ha, ca), (b, hb, cb) = out
+            assert ca["reflection"] > 0 and ca == cb and torch.equal(ha, hb)
+            d = (a - b).abs()
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01
+    finally:
+        renderer.set_reflect_table(True)
+
+
 def test_queue_spill_changes_only_summation_order(renderer):
     """Refractive scenes: a wave whose work queue is full sets records aside in device memory
     (RT_OPT_QUEUE_SPILL, default) or only shrinks its passes.  Same tree nodes either way: identical ray counts and
