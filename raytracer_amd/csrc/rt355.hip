@@ -23,7 +23,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt355.h"
@@ -126,6 +128,11 @@ struct RenderParams {
   // masks of the spheres a ray that leaves the object in a direction of the bucket can hit (nearest_table)
   const uint2* refl_tab;
   int refl_dim, refl_pairs;
+  // the same table as lists, for scenes with too many spheres for masks (list_dim = 0: none): entry [object][bucket] is the
+  // run of 4-index chunks list_start[e] .. list_start[e + 1] of list_items (uint16 indices, ascending, padded with 0xFFFF)
+  const uint32_t* list_start;
+  const uint2* list_items;
+  int list_dim;
   const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
   int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
@@ -159,6 +166,9 @@ struct RenderParams {
 #ifndef RT_REFL_TABLE_FROM
 #define RT_REFL_TABLE_FROM 4    // reflection rays: scenes with at least this many spheres get a direction table (nearest_table);
                                 // measured on config 2 (8 spheres): +1.6 % over the plain scan, 64 spheres: +33 %
+#endif
+#ifndef RT_REFL_LIST_DIM
+#define RT_REFL_LIST_DIM 16     // scenes with too many spheres for masks (>= the grid's threshold): buckets per face edge of the list form
 #endif
 #ifndef RT_VIS_TILES
 #define RT_VIS_TILES 4     // 8x8 tiles (pixels per lane) of one visibility-pass wave: 2 -> +5 %, 4 -> +8 % on config 2 (87 VGPRs)
@@ -516,24 +526,27 @@ __device__ __forceinline__ void nearest_grid(const RenderParams& p, const float4
 // order, testing each with the expressions of nearest_hit() — same distances, same lowest-index rule on ties, so the
 // result is the plain scan's (RT_OPT_REFLECT_TABLE off, test).  Only ~5 % of reflection rays hit anything and a
 // mask holds 0.5 spheres on average at 64 spheres: the wave loops max-over-lanes(popcount) ~ 4 times instead of 64.
-__device__ __forceinline__ void nearest_table(const RenderParams& p, const float4* __restrict__ sg, int obj, float ox,
-                                              float oy, float oz, float dx, float dy, float dz, float& best_t,
-                                              int& best_i) {
-  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-  best_t = INFINITY;
-  best_i = -1;
-  // cube-map bucket of the direction: major axis m (face 2 m + sign), the other two components over |major|
+// cube-map bucket of a direction: major axis m (face 2 m + sign), the other two components over |major|
+__device__ __forceinline__ int direction_bucket(float dx, float dy, float dz, int B) {
   const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
   const bool mx = ax >= ay && ax >= az, my = !mx && ay >= az;
   const float major = mx ? dx : my ? dy : dz;
   const float a = mx ? dy : my ? dz : dx, b = mx ? dz : my ? dx : dy;
   const int m = mx ? 0 : my ? 1 : 2;
   const float inv = frcp(fabsf(major));
-  const int B = p.refl_dim;
   const float hB = 0.5f * float(B);
   const int ix = min(B - 1, max(0, int(fmaf(a * inv, hB, hB))));
   const int iy = min(B - 1, max(0, int(fmaf(b * inv, hB, hB))));
-  const int bucket = ((2 * m + (major < 0.0f ? 1 : 0)) * B + iy) * B + ix;
+  return ((2 * m + (major < 0.0f ? 1 : 0)) * B + iy) * B + ix;
+}
+__device__ __forceinline__ void nearest_table(const RenderParams& p, const float4* __restrict__ sg, int obj, float ox,
+                                              float oy, float oz, float dx, float dy, float dz, float& best_t,
+                                              int& best_i) {
+  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  best_t = INFINITY;
+  best_i = -1;
+  const int B = p.refl_dim;
+  const int bucket = direction_bucket(dx, dy, dz, B);
   const uint2* row = p.refl_tab + (size_t(obj) * size_t(6 * B * B) + size_t(bucket)) * size_t(p.refl_pairs);
   for (int w = 0; w < p.refl_pairs; ++w) {
     const uint2 mask = row[w];
@@ -549,6 +562,39 @@ __device__ __forceinline__ void nearest_table(const RenderParams& p, const float
         const float t = sphere_t_exact(sg[j], ox, oy, oz, dx, dy, dz, inv_a, dl);
         if (dl >= 0.0f && t > 0.0f && t < best_t) { best_t = t; best_i = j; }
       }
+    }
+  }
+}
+
+// The same for scenes with 256 spheres or more, where a mask per entry would be mostly zeros: an entry is a short
+// list of sphere indices, stored in chunks of four (one 8-byte load; the next chunk is requested before this one is
+// tested).  Replaces the grid walk (nearest_grid, kept behind RT_OPT_REFLECT_TABLE = 0): no cell-to-cell stepping,
+// two dependent loads per ray instead of two per cell.
+__device__ __forceinline__ void nearest_list(const RenderParams& p, const float4* __restrict__ sg, int obj, float ox,
+                                             float oy, float oz, float dx, float dy, float dz, float& best_t,
+                                             int& best_i) {
+  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  best_t = INFINITY;
+  best_i = -1;
+  const int B = p.list_dim;
+  const uint32_t* st = p.list_start + size_t(obj) * size_t(6 * B * B) + size_t(direction_bucket(dx, dy, dz, B));
+  uint32_t c = st[0];
+  const uint32_t e = st[1];
+  uint2 nxt = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  if (c < e) nxt = p.list_items[c];
+  auto test = [&](uint32_t j) {
+    if (j != 0xFFFFu) {
+      float dl;
+      const float t = sphere_t_exact(sg[j], ox, oy, oz, dx, dy, dz, inv_a, dl);
+      if (dl >= 0.0f && t > 0.0f && t < best_t) { best_t = t; best_i = int(j); }
+    }
+  };
+  while (__ballot(c < e) != 0ull) {
+    if (c < e) {
+      const uint2 cur = nxt;
+      ++c;
+      if (c < e) nxt = p.list_items[c];
+      test(cur.x & 0xFFFFu); test(cur.x >> 16); test(cur.y & 0xFFFFu); test(cur.y >> 16);
     }
   }
 }
@@ -2283,7 +2329,11 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
           float t;
           int idx2, face;
           ++n_trace;
-          if constexpr (GRID) { nearest_grid(p, sg, ox, oy, oz, dx, dy, dz, t, idx2); face = 0; }
+          if constexpr (GRID) {
+            if (p.list_dim > 0) nearest_list(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2);
+            else nearest_grid(p, sg, ox, oy, oz, dx, dy, dz, t, idx2);
+            face = 0;
+          }
           else if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2); face = 0; }
           else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, dx, dy, dz, t, idx2, face);
           if (idx2 >= 0) {
@@ -2692,6 +2742,10 @@ struct rt_ctx {
   uint2* d_refl_tab = nullptr;        // direction table of reflection rays (build_reflect_table; grown on demand)
   size_t refl_tab_bytes = 0;
   int refl_dim = 0, refl_pairs = 0;
+  uint32_t* d_list_start = nullptr;   // the table as lists (build_reflect_lists; grown on demand)
+  uint2* d_list_items = nullptr;
+  size_t list_start_bytes = 0, list_items_bytes = 0;
+  int list_dim = 0;
   bool reflect_table = true;          // RT_OPT_REFLECT_TABLE
   bool sphere_grid = true;            // RT_OPT_SPHERE_GRID
   int queue_spill = 1;                // RT_OPT_QUEUE_SPILL: 0 off, 1 automatic depth, 2.. = at most that many blocks per wave
@@ -2856,11 +2910,9 @@ int reflect_table_dim(int n) {
   for (int B : {16, 8}) if (size_t(n) * size_t(6 * B * B) * pairs * 8 <= kReflTabMaxBytes) return B;
   return 4;
 }
-void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& tab) {
-  const int pairs = (n + 63) / 64, nb = 6 * B * B;
-  tab.assign(size_t(n) * size_t(nb) * size_t(pairs), make_uint2(0u, 0u));
-  struct Patch { double x, y, z, ch, sh, h; };
-  std::vector<Patch> patch(size_t(nb), Patch{0, 0, 0, 0, 0, 0});
+struct DirPatch { double x, y, z, ch, sh, h; };   // bounding cone of a bucket: unit axis, cos / sin of its half-angle h (margin included)
+std::vector<DirPatch> direction_patches(int B) {
+  std::vector<DirPatch> patch(size_t(6 * B * B), DirPatch{0, 0, 0, 0, 0, 0});
   auto dir = [](int f, double a, double b, double* v) {   // the kernel's convention: face 2 m + (major < 0), a = next axis, b = the one after
     const int m = f >> 1;
     v[m] = (f & 1) ? -1.0 : 1.0; v[(m + 1) % 3] = a; v[(m + 2) % 3] = b;
@@ -2878,30 +2930,116 @@ void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& t
           cmin = std::min(cmin, c[0] * v[0] + c[1] * v[1] + c[2] * v[2]);
         }
         const double h = std::acos(std::max(-1.0, std::min(1.0, cmin))) + 1e-3;
-        patch[size_t((f * B + iy) * B + ix)] = Patch{c[0], c[1], c[2], std::cos(h), std::sin(h), h};
+        patch[size_t((f * B + iy) * B + ix)] = DirPatch{c[0], c[1], c[2], std::cos(h), std::sin(h), h};
       }
+  return patch;
+}
+// The buckets of object k, sphere by sphere: emit(bucket, j) for every bucket that lists j, j ascending.  Buckets are
+// looked at through a coarse level (4 x 4 patches per face, each the union of (B/4)^2 buckets) when B allows it:
+// most spheres reach into one or two coarse patches only.
+template <typename Emit>
+void reflect_buckets_of(const float* geom4, int n, int k, int B, const std::vector<DirPatch>& fine,
+                        const std::vector<DirPatch>& coarse, Emit&& emit) {
   const double kPi = 3.14159265358979323846;
-  for (int k = 0; k < n; ++k) {
-    const double kx = geom4[4 * k], ky = geom4[4 * k + 1], kz = geom4[4 * k + 2];
-    const double rho = std::sqrt(double(geom4[4 * k + 3])) * 1.001 + 2e-3;
-    for (int j = 0; j < n; ++j) {
-      if (j == k) continue;
-      const double vx = geom4[4 * j] - kx, vy = geom4[4 * j + 1] - ky, vz = geom4[4 * j + 2] - kz;
-      const double d = std::sqrt(vx * vx + vy * vy + vz * vz);
-      const double reach = rho + std::sqrt(double(geom4[4 * j + 3])) * 1.001 + 1e-3;
-      const bool all = !(d > reach * 1.0001);
-      const double sn = all ? 1.0 : reach / d, theta = all ? kPi : std::asin(sn), cs = std::sqrt(std::max(0.0, 1.0 - sn * sn));
-      const double ux = all ? 0.0 : vx / d, uy = all ? 0.0 : vy / d, uz = all ? 0.0 : vz / d;
+  const int nb = 6 * B * B, Bc = coarse.empty() ? 0 : 4, sub = Bc ? B / Bc : 0;
+  const double kx = geom4[4 * k], ky = geom4[4 * k + 1], kz = geom4[4 * k + 2];
+  const double rho = std::sqrt(double(geom4[4 * k + 3])) * 1.001 + 2e-3;
+  for (int j = 0; j < n; ++j) {
+    if (j == k) continue;
+    const double vx = geom4[4 * j] - kx, vy = geom4[4 * j + 1] - ky, vz = geom4[4 * j + 2] - kz;
+    const double d = std::sqrt(vx * vx + vy * vy + vz * vz);
+    const double reach = rho + std::sqrt(double(geom4[4 * j + 3])) * 1.001 + 1e-3;
+    const bool all = !(d > reach * 1.0001);
+    const double sn = all ? 1.0 : reach / d, theta = all ? kPi : std::asin(sn), cs = std::sqrt(std::max(0.0, 1.0 - sn * sn));
+    const double ux = all ? 0.0 : vx / d, uy = all ? 0.0 : vy / d, uz = all ? 0.0 : vz / d;
+    // angle(axis, u) <= theta + h  <=>  axis.u >= cos(theta + h)   (theta + h < pi)
+    auto reaches = [&](const DirPatch& P) {
+      return all || theta + P.h >= kPi || P.x * ux + P.y * uy + P.z * uz >= cs * P.ch - sn * P.sh;
+    };
+    if (!Bc) {
+      for (int b = 0; b < nb; ++b) if (reaches(fine[size_t(b)])) emit(b, j);
+      continue;
+    }
+    for (int f = 0; f < 6; ++f)
+      for (int cy = 0; cy < Bc; ++cy)
+        for (int cx = 0; cx < Bc; ++cx) {
+          if (!reaches(coarse[size_t((f * Bc + cy) * Bc + cx)])) continue;
+          for (int iy = cy * sub; iy < (cy + 1) * sub; ++iy)
+            for (int ix = cx * sub; ix < (cx + 1) * sub; ++ix) {
+              const int b = (f * B + iy) * B + ix;
+              if (reaches(fine[size_t(b)])) emit(b, j);
+            }
+        }
+  }
+}
+void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& tab) {
+  const int pairs = (n + 63) / 64, nb = 6 * B * B;
+  tab.assign(size_t(n) * size_t(nb) * size_t(pairs), make_uint2(0u, 0u));
+  const std::vector<DirPatch> fine = direction_patches(B);
+  const std::vector<DirPatch> coarse = (B > 4 && B % 4 == 0) ? direction_patches(4) : std::vector<DirPatch>();
+  for (int k = 0; k < n; ++k)
+    reflect_buckets_of(geom4, n, k, B, fine, coarse, [&](int b, int j) {
+      uint2& e = tab[(size_t(k) * size_t(nb) + size_t(b)) * size_t(pairs) + size_t(j >> 6)];
+      if (j & 32) e.y |= 1u << (j & 31); else e.x |= 1u << (j & 31);
+    });
+}
+// The table as lists (nearest_list): start[k * nb + b] .. start[k * nb + b + 1] are the 4-index chunks of entry
+// [k][b] in `items` (ascending sphere indices, the last chunk padded with 0xFFFF).  Objects are independent, so the
+// build runs on several threads.  Returns false — no table, the grid walk stays — if the lists would exceed
+// kReflListMaxChunks (a scene where most spheres reach most directions of most objects: huge or interlocked spheres).
+constexpr int kReflListDim = RT_REFL_LIST_DIM;
+constexpr size_t kReflListMaxChunks = size_t(32) << 20;   // 256 MB of indices
+bool build_reflect_lists(const float* geom4, int n, int B, std::vector<uint32_t>& start, std::vector<uint2>& items) {
+  const int nb = 6 * B * B;
+  const std::vector<DirPatch> fine = direction_patches(B);
+  const std::vector<DirPatch> coarse = (B > 4 && B % 4 == 0) ? direction_patches(4) : std::vector<DirPatch>();
+  std::vector<std::vector<uint32_t>> counts{static_cast<size_t>(n)};      // per object: chunks of each bucket
+  std::vector<std::vector<uint2>> chunks{static_cast<size_t>(n)};        // per object: its buckets' chunks, bucket after bucket
+  std::atomic<int> next(0);
+  std::atomic<size_t> total(0);
+  auto work = [&]() {
+    std::vector<std::vector<uint16_t>> rows{static_cast<size_t>(nb)};
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= n || total.load() > kReflListMaxChunks) return;
+      for (auto& r : rows) r.clear();
+      reflect_buckets_of(geom4, n, k, B, fine, coarse, [&](int b, int j) { rows[size_t(b)].push_back(uint16_t(j)); });
+      std::vector<uint32_t>& cnt = counts[size_t(k)];
+      std::vector<uint2>& out = chunks[size_t(k)];
+      cnt.assign(size_t(nb), 0u);
       for (int b = 0; b < nb; ++b) {
-        const Patch& P = patch[size_t(b)];
-        // angle(axis, u) <= theta + h  <=>  axis.u >= cos(theta + h)   (theta + h < pi)
-        if (all || theta + P.h >= kPi || P.x * ux + P.y * uy + P.z * uz >= cs * P.ch - sn * P.sh) {
-          uint2& e = tab[(size_t(k) * size_t(nb) + size_t(b)) * size_t(pairs) + size_t(j >> 6)];
-          if (j & 32) e.y |= 1u << (j & 31); else e.x |= 1u << (j & 31);
+        const std::vector<uint16_t>& r = rows[size_t(b)];
+        cnt[size_t(b)] = uint32_t((r.size() + 3) / 4);
+        for (size_t i = 0; i < r.size(); i += 4) {
+          uint32_t v[4];
+          for (size_t q = 0; q < 4; ++q) v[q] = i + q < r.size() ? r[i + q] : 0xFFFFu;
+          out.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16)));
         }
       }
+      total.fetch_add(out.size());
     }
+  };
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int n_threads = int(std::max(1u, std::min(16u, std::min(hw ? hw : 1u, unsigned(n / 64 + 1)))));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  if (total.load() > kReflListMaxChunks) return false;
+  start.assign(size_t(n) * size_t(nb) + 1, 0u);
+  items.clear();
+  items.reserve(total.load() + 1);
+  size_t at = 0;
+  for (int k = 0; k < n; ++k) {
+    for (int b = 0; b < nb; ++b) {
+      start[size_t(k) * size_t(nb) + size_t(b)] = uint32_t(at);
+      at += counts[size_t(k)][size_t(b)];
+    }
+    items.insert(items.end(), chunks[size_t(k)].begin(), chunks[size_t(k)].end());
   }
+  start.back() = uint32_t(at);
+  items.push_back(make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));   // (never empty: hipMalloc of zero bytes)
+  return true;
 }
 
 // Occluder table for lighting()'s shadow scan: bit c of row k says that sphere c can be hit by SOME
@@ -3098,8 +3236,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.glass_bits = ctx->d_glass_bits;
   p.grid_start = ctx->d_grid_start; p.grid_items = ctx->d_grid_items; p.grid_big = ctx->d_grid_big;
   p.grid_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->grid_dim;
+  p.list_start = ctx->d_list_start; p.list_items = ctx->d_list_items;
+  p.list_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->list_dim;
   p.refl_tab = ctx->d_refl_tab; p.refl_pairs = ctx->refl_pairs;
-  p.refl_dim = (cubes || !stream_kernel || p.grid_dim > 0) ? 0 : ctx->refl_dim;
+  p.refl_dim = (cubes || !stream_kernel || p.grid_dim > 0 || p.list_dim > 0) ? 0 : ctx->refl_dim;
   p.grid_n_big = ctx->grid_n_big;
   for (int k = 0; k < 3; ++k) {
     p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];
@@ -3231,7 +3371,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi), vgrid, dim3(kBlock), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples)
-          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
+          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0 || p.list_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples)   // (never MULTI)
           hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
                              ctx->stream, p);
@@ -3351,6 +3491,8 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_occl) (void)hipFree(ctx->d_occl);
   if (ctx->d_glass_bits) (void)hipFree(ctx->d_glass_bits);
   if (ctx->d_refl_tab) (void)hipFree(ctx->d_refl_tab);
+  if (ctx->d_list_start) (void)hipFree(ctx->d_list_start);
+  if (ctx->d_list_items) (void)hipFree(ctx->d_list_items);
   if (ctx->d_grid_start) (void)hipFree(ctx->d_grid_start);
   if (ctx->d_grid_items) (void)hipFree(ctx->d_grid_items);
   if (ctx->d_grid_big) (void)hipFree(ctx->d_grid_big);
@@ -3458,9 +3600,32 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     build_occluder_table(geom4, n_spheres, L, occl, ctx->occluder_table);
     RT_HIP(ctx, hipMemcpy(ctx->d_occl, occl.data(), sizeof(uint32_t) * occl.size(), hipMemcpyHostToDevice));
   }
+  ctx->list_dim = 0;
+  if (ctx->reflect_table && n_spheres >= kGridFrom) {   // many spheres: the direction table as lists; the grid only if that fails
+    std::vector<uint32_t> start;
+    std::vector<uint2> items;
+    if (build_reflect_lists(geom4, n_spheres, kReflListDim, start, items)) {
+      const size_t sb = start.size() * sizeof(uint32_t), ib = items.size() * sizeof(uint2);
+      if (sb > ctx->list_start_bytes) {
+        if (ctx->d_list_start) (void)hipFree(ctx->d_list_start);
+        ctx->d_list_start = nullptr; ctx->list_start_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_list_start, sb));
+        ctx->list_start_bytes = sb;
+      }
+      if (ib > ctx->list_items_bytes) {
+        if (ctx->d_list_items) (void)hipFree(ctx->d_list_items);
+        ctx->d_list_items = nullptr; ctx->list_items_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_list_items, ib));
+        ctx->list_items_bytes = ib;
+      }
+      RT_HIP(ctx, hipMemcpy(ctx->d_list_start, start.data(), sb, hipMemcpyHostToDevice));
+      RT_HIP(ctx, hipMemcpy(ctx->d_list_items, items.data(), ib, hipMemcpyHostToDevice));
+      ctx->list_dim = kReflListDim;
+    }
+  }
   {
     SphereGrid grid;
-    if (ctx->sphere_grid) build_sphere_grid(geom4, n_spheres, grid);
+    if (ctx->sphere_grid && ctx->list_dim == 0) build_sphere_grid(geom4, n_spheres, grid);
     if (grid.dim > 0) {
       RT_HIP(ctx, hipMemcpy(ctx->d_grid_start, grid.start.data(), sizeof(uint32_t) * grid.start.size(), hipMemcpyHostToDevice));
       if (!grid.items.empty())
@@ -3481,6 +3646,8 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
       const size_t bytes = tab.size() * sizeof(uint2);
       if (bytes > ctx->refl_tab_bytes) {
         if (ctx->d_refl_tab) (void)hipFree(ctx->d_refl_tab);
+  if (ctx->d_list_start) (void)hipFree(ctx->d_list_start);
+  if (ctx->d_list_items) (void)hipFree(ctx->d_list_items);
         ctx->d_refl_tab = nullptr; ctx->refl_tab_bytes = 0;
         RT_HIP(ctx, hipMalloc(&ctx->d_refl_tab, bytes));
         ctx->refl_tab_bytes = bytes;
