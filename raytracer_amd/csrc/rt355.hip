@@ -118,6 +118,10 @@ struct RenderParams {
   const uint32_t* glass_bits;  // [ceil(n_spheres / 32)] bit c: sphere c is refractive (REFR kernels' shadow scan)
   const uint32_t* occl;  // [objects][occl_words] bit c of row k: sphere c can shadow some point of object k (host table)
   int occl_words;        // ceil(n_spheres / 32)
+  // the same table as lists, for scenes with many spheres (the GRID kernels; 32 .. 64 mostly empty words per row otherwise):
+  // row k is the run of 4-index chunks occl_start[k] .. occl_start[k + 1] of occl_items (uint16, ascending, padded with 0xFFFF)
+  const uint32_t* occl_start;
+  const uint2* occl_items;
   // uniform grid over the spheres for reflection rays of many-sphere scenes (grid_dim = 0: none)
   const uint32_t* grid_start;   // [grid_dim^3 + 1] first entry of each cell in grid_items
   const uint16_t* grid_items;   // sphere indices, ascending within a cell
@@ -870,11 +874,11 @@ __device__ __forceinline__ void light_colour(const DevLights& L, const LightSums
   lb = fmaf(mb * L.pcol[2], pk, L.pcol[2] * psk) + L.acol[2] * (ak + ask);
 }
 
-template <int MODE, int B, bool REFR = false, bool CUBES = false>
+template <int MODE, int B, bool REFR = false, bool CUBES = false, bool LIST = false>
 __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* __restrict__ sg,
                                          const float4* __restrict__ gg, const float2* __restrict__ refr,
                                          const uint32_t* __restrict__ glass_bits,
-                                         const uint32_t* __restrict__ occl_row, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
+                                         const uint32_t* __restrict__ occl_row, const uint2* __restrict__ occl_items, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          uint32_t level_key) {
 #if RT_CULL_STATS
@@ -984,6 +988,62 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       const float cos2_t = fmaf(-sin_t, sin_t, 1.0f);
       const float sin2_t = sin_t * sin_t * 1.0078125f;
       const bool wide = !(sin_t < 0.99f);   // P within (about) the light's bounding sphere: rays go anywhere
+      // one candidate sphere against this lane's cone (and its point-light ray): the verdict's sign bit is CLEAR if the
+      // sphere can matter
+      auto cone_cull = [&](const float4 g) -> uint32_t {
+        const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
+        const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
+        const float d2 = c + g.w, r = fsqrt(g.w);
+        const float along = fmaf(cz, axz, fmaf(cy, axy, cx * axx));
+        const float al2 = along * along, perp2 = d2 - al2;
+        const float rhs = fmaf(along, sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
+        const float t2 = fmaf(rhs, rhs, -(perp2 * cos2_t));
+        const float e = fmaf(al2, cos2_t, -(perp2 * sin2_t));
+        uint32_t no = __float_as_uint(rhs) | __float_as_uint(t2) | (__float_as_uint(along) & ~__float_as_uint(e));
+        if (wide) no = 0u;
+        if (base == 0) {   // the point-light ray (k = 0): nb > 0 and nb^2 - c + 1.5 thr >= 0
+          const float nb = fmaf(cz, Lz[0], fmaf(cy, Ly[0], cx * Lx[0]));
+          const float q = fmaf(nb, nb, fmaf(d2, 1.5f / 262144.0f, -c));
+          no &= __float_as_uint(nb) | __float_as_uint(q);
+        }
+        return no | __float_as_uint(c);      // origin inside the sphere: never hit
+      };
+      if constexpr (LIST) {
+        // Many spheres: the object's candidates come as a list (chunks of four indices, the next chunk requested
+        // before this one is looked at) instead of 32 .. 64 mostly empty mask words, each a load of its own.
+        // Up to 32 candidates are culled at a time; the survivors' positions go into `rel` and are tested below.
+        uint32_t c = occl_row[0];
+        const uint32_t e = occl_row[1];
+        while (__ballot(c < e) != 0ull) {
+          const uint32_t c0 = c;
+          uint32_t rel = 0u;
+          uint2 nxt = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+          if (c < e) nxt = occl_items[c];
+#pragma nounroll
+          for (int grp = 0; grp < 8; ++grp) {
+            if (__ballot(c < e) == 0ull) break;
+            if (c < e) {
+              const uint2 cur = nxt;
+              ++c;
+              if (c < e) nxt = occl_items[c];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t j = ((i & 2) ? cur.y : cur.x) >> ((i & 1) * 16) & 0xFFFFu;
+                if (j != 0xFFFFu) rel |= (~cone_cull(sg[j]) >> 31) << (4 * grp + i);
+              }
+            }
+          }
+          while (__ballot(rel != 0u) != 0ull) {
+            if (rel != 0u) {
+              const int pos = __ffs(int(rel)) - 1;
+              rel &= rel - 1u;
+              const uint2 ch = occl_items[c0 + uint32_t(pos >> 2)];
+              const uint32_t j = ((pos & 2) ? ch.y : ch.x) >> ((pos & 1) * 16) & 0xFFFFu;
+              test_sphere(sg[j]);
+            }
+          }
+        }
+      } else
       for (int cbase = 0, word = 0; cbase < n; cbase += 32, ++word) {
         // candidates: the spheres that can shadow SOME point of the object this lane shades (a table
         // built at scene upload: every ray from the object towards a light lies in one cone, and few
@@ -1148,7 +1208,7 @@ struct MaterialInRegisters {   // the pixel kernel: plain loads, issued early
   __device__ __forceinline__ void request(int idx) { m = p.mat[idx]; spec = p.spec[idx]; }
   __device__ __forceinline__ void load(float4& m_out, float& spec_out) { m_out = m; spec_out = spec; }
 };
-template <int MODE, bool CUBES = false, typename LateState>
+template <int MODE, bool CUBES = false, bool LIST = false, typename LateState>
 __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* __restrict__ sg, int idx,
                                           float px, float py, float pz, float& dx, float& dy, float& dz,
                                           uint32_t level_key, float& tr, float& tg, float& tb,
@@ -1159,7 +1219,8 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-  const LightSums w = lighting<MODE, kShadowBatch, false, CUBES>(p.L, sg, p.geom, nullptr, nullptr, p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+  const LightSums w = lighting<MODE, kShadowBatch, false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr,
+                               LIST ? p.occl_start + idx : p.occl + size_t(idx) * size_t(p.occl_words), p.occl_items, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                level_key);
   float4 m;
   float spec;
@@ -2215,7 +2276,7 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
             const int idx = meta_object(meta);
             surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
             sx = fmaf(nx, 0.001f, px); sy = fmaf(ny, 0.001f, py); sz = fmaf(nz, 0.001f, pz);
-            const LightSums lw = lighting<MODE, kRefrShadowBatch, true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl + size_t(idx) * size_t(p.occl_words), p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
+            const LightSums lw = lighting<MODE, kRefrShadowBatch, true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl + size_t(idx) * size_t(p.occl_words), nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
                                     sx, sy, sz, mix(pixel_key, uint32_t(meta_level(meta) + 1)));
             // (material, record state and the meta word come in BEHIND the shadow loops, as in the opaque path:
             // the 13-ray batch leaves no registers for them)
@@ -2318,7 +2379,7 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
           const RenderParams& p = params_here();                     // the lights and tables of lighting(): dead after it
           LateFromRecord late{p, late_state, q, e, meta, base, lane_here()};
           const uint32_t level_key = mix(pixel_key, uint32_t(meta_level(meta) + 1));
-          cont = shade_hit<MODE, CUBES>(p, sg, meta_object(meta), px, py, pz, dx, dy, dz, level_key,
+          cont = shade_hit<MODE, CUBES, GRID>(p, sg, meta_object(meta), px, py, pz, dx, dy, dz, level_key,
                                         tr, tg, tb, ar, ag, ab, ox, oy, oz, late);
         }
         const RenderParams& p = params_here();
@@ -2742,6 +2803,9 @@ struct rt_ctx {
   uint2* d_refl_tab = nullptr;        // direction table of reflection rays (build_reflect_table; grown on demand)
   size_t refl_tab_bytes = 0;
   int refl_dim = 0, refl_pairs = 0;
+  uint32_t* d_occl_start = nullptr;   // occluder table rows as lists (scenes with >= kGridFrom spheres): [RT_MAX_SPHERES + 1]
+  uint2* d_occl_items = nullptr;      // (grown on demand)
+  size_t occl_items_bytes = 0;
   uint32_t* d_list_start = nullptr;   // the table as lists (build_reflect_lists; grown on demand)
   uint2* d_list_items = nullptr;
   size_t list_start_bytes = 0, list_items_bytes = 0;
@@ -3233,6 +3297,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
   p.cubes = ctx->d_cubes; p.n_cubes = ctx->n_cubes;
   p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32;
+  p.occl_start = ctx->d_occl_start; p.occl_items = ctx->d_occl_items;
   p.glass_bits = ctx->d_glass_bits;
   p.grid_start = ctx->d_grid_start; p.grid_items = ctx->d_grid_items; p.grid_big = ctx->d_grid_big;
   p.grid_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->grid_dim;
@@ -3446,6 +3511,7 @@ int rt_create(int device_id, rt_ctx** out) {
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
     return bail(e, "hipMalloc");
+  if ((e = hipMalloc(&ctx->d_occl_start, sizeof(uint32_t) * (RT_MAX_SPHERES + 1))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_glass_bits, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMalloc(&ctx->d_frames, sizeof(FrameRec) * kMaxBatch)) != hipSuccess) return bail(e, "hipMalloc");
@@ -3491,6 +3557,8 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_occl) (void)hipFree(ctx->d_occl);
   if (ctx->d_glass_bits) (void)hipFree(ctx->d_glass_bits);
   if (ctx->d_refl_tab) (void)hipFree(ctx->d_refl_tab);
+  if (ctx->d_occl_start) (void)hipFree(ctx->d_occl_start);
+  if (ctx->d_occl_items) (void)hipFree(ctx->d_occl_items);
   if (ctx->d_list_start) (void)hipFree(ctx->d_list_start);
   if (ctx->d_list_items) (void)hipFree(ctx->d_list_items);
   if (ctx->d_grid_start) (void)hipFree(ctx->d_grid_start);
@@ -3599,6 +3667,36 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     std::vector<uint32_t> occl;
     build_occluder_table(geom4, n_spheres, L, occl, ctx->occluder_table);
     RT_HIP(ctx, hipMemcpy(ctx->d_occl, occl.data(), sizeof(uint32_t) * occl.size(), hipMemcpyHostToDevice));
+    if (n_spheres >= kGridFrom) {   // the GRID kernels read the rows as lists (lighting<..., LIST>)
+      const int words = (n_spheres + 31) / 32;
+      std::vector<uint32_t> start(size_t(n_spheres) + 1, 0u);
+      std::vector<uint2> items;
+      for (int k = 0; k < n_spheres; ++k) {
+        start[size_t(k)] = uint32_t(items.size());
+        uint32_t v[4];
+        int fill = 0;
+        for (int c = 0; c < n_spheres; ++c)
+          if ((occl[size_t(k) * size_t(words) + size_t(c >> 5)] >> (c & 31)) & 1u) {
+            v[fill++] = uint32_t(c);
+            if (fill == 4) { items.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16))); fill = 0; }
+          }
+        if (fill) {
+          for (int q = fill; q < 4; ++q) v[q] = 0xFFFFu;
+          items.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16)));
+        }
+      }
+      start[size_t(n_spheres)] = uint32_t(items.size());
+      items.push_back(make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
+      const size_t ib = items.size() * sizeof(uint2);
+      if (ib > ctx->occl_items_bytes) {
+        if (ctx->d_occl_items) (void)hipFree(ctx->d_occl_items);
+        ctx->d_occl_items = nullptr; ctx->occl_items_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_occl_items, ib));
+        ctx->occl_items_bytes = ib;
+      }
+      RT_HIP(ctx, hipMemcpy(ctx->d_occl_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      RT_HIP(ctx, hipMemcpy(ctx->d_occl_items, items.data(), ib, hipMemcpyHostToDevice));
+    }
   }
   ctx->list_dim = 0;
   if (ctx->reflect_table && n_spheres >= kGridFrom) {   // many spheres: the direction table as lists; the grid only if that fails
@@ -3646,8 +3744,6 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
       const size_t bytes = tab.size() * sizeof(uint2);
       if (bytes > ctx->refl_tab_bytes) {
         if (ctx->d_refl_tab) (void)hipFree(ctx->d_refl_tab);
-  if (ctx->d_list_start) (void)hipFree(ctx->d_list_start);
-  if (ctx->d_list_items) (void)hipFree(ctx->d_list_items);
         ctx->d_refl_tab = nullptr; ctx->refl_tab_bytes = 0;
         RT_HIP(ctx, hipMalloc(&ctx->d_refl_tab, bytes));
         ctx->refl_tab_bytes = bytes;
