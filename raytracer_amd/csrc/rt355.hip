@@ -1637,8 +1637,10 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     const long long frame_px = (long long)frame * p.frame_stride_px;
     const bool whole = rowR + 8 * kVisRows <= p.n_rows && p.nx - col0 >= 8 * NT;
     const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : p.defer_output != 0);
-    const bool black_owed = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && whole &&
-                            (p.nx & 3) == 0 && (frame_px & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
+    // (MULTI: the launch of the last sample writes the black of tiles that NO sample hit — `present` knows)
+    const bool black_owed = (MULTI ? p.sample_index + 1 == p.n_samples : p.n_samples == 1) && !p.out_f32 && !p.out_hit &&
+                            !p.defer_output && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
     if ((nothing_owed || black_owed) && p.n_spheres <= 64) {
       bool any = false;
       if (p.n_spheres > 0) {
@@ -1649,6 +1651,13 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
         const int yb = (p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + last : row_of(p, last)) + 1;
         const RayCone cone = bundle_cone(p, fr.cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
         any = __ballot(lane < p.n_spheres && sphere_in_cone(sphere, cone, fr.cam.origin[0], fr.cam.origin[1], fr.cam.origin[2])) != 0ull;
+      }
+      if constexpr (MULTI) {
+        if (!any && black_owed) {   // did an earlier sample hit a tile of the region?  (lane l: tile l % NT of block l / NT)
+          const uint32_t id = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) +
+                              uint32_t((rowR >> 3) + lane / NT) * uint32_t(p.tile_pitch) + uint32_t((col0 >> 3) + lane % NT);
+          any = __ballot(lane < NT * kVisRows && p.present[id] != 0ull) != 0ull;
+        }
       }
       if (!any) {
         if (black_owed) {
