@@ -51,6 +51,10 @@
 #ifndef RT_SHADOW_CHEAP
 #define RT_SHADOW_CHEAP 1 // shadow scan: plain discriminant + exact fallback in the ambiguous band
 #endif
+#ifndef RT_LIGHT_FAST
+#define RT_LIGHT_FAST 1   // lighting(), bit 0 (on): light positions relative to P formed once per point (+1.2 %); bit 1 (off: measured -3 %, the
+                          // kernel then spills 10 VGPRs around the shadow loops): mirrored view vector and sign-bit selects in the shading
+#endif
 #ifndef RT_GEOM_SRC
 #define RT_GEOM_SRC 0     // shadow scan reads spheres from: 0 LDS, 1 LDS prefetched, 2 scalar loads
 #endif
@@ -850,8 +854,10 @@ static __device__ unsigned long long g_dbg[4];
 #define g_dbg_rel dbg_rel_
 #define g_dbg_lanes dbg_lanes_
 #define g_dbg_iters dbg_iters_
-static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigned i) {
+#define g_dbg_turns dbg_turns_
+static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigned i, unsigned t) {
   atomicAdd(&g_dbg[0], (unsigned long long)r); atomicAdd(&g_dbg[1], (unsigned long long)l); atomicAdd(&g_dbg[2], (unsigned long long)i);
+  atomicAdd(&g_dbg[3], (unsigned long long)t);
 }
 #endif
 // What the shadow rays of one shading point leave behind: unshadowed diffuse / specular weights of the point
@@ -860,6 +866,7 @@ static __device__ __forceinline__ void dbg_flush(unsigned r, unsigned l, unsigne
 // registers across them.
 struct LightSums {
   float pd, ps, ad, as;
+  float rx, ry, rz;   // D - 2 (D.N) N: the mirrored direction (:246), which lighting() forms for the specular terms anyway
 };
 __device__ __forceinline__ void light_colour(const DevLights& L, const LightSums& w, float mr, float mg, float mb,
                                              float spec, float& lr, float& lg, float& lb) {
@@ -882,12 +889,22 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          uint32_t level_key) {
 #if RT_CULL_STATS
-  unsigned dbg_rel_ = 0, dbg_lanes_ = 0, dbg_iters_ = 0;
+  unsigned dbg_rel_ = 0, dbg_lanes_ = 0, dbg_iters_ = 0, dbg_turns_ = 0;
 #endif
   const int nrays = 1 + L.ns;
   const float vdn = -(fmaf(dz, nz, fmaf(dy, ny, dx * nx)));  // view . normal, view = -D (:257)
   float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
   float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
+#if RT_LIGHT_FAST
+  // Per point, not per ray: the area light's corner seen from P — sample j is  A + u (r_u - 0.5) + v (r_v - 0.5) - P
+  // = (A - P - 1.5 (u + v)) + u (1 + r_u) + v (1 + r_v), and the draws come as 1 + r — and the mirrored view vector:
+  // view . (L - N (2 L.N))  (:192-193 / :207-208) = -(D - 2 (D.N) N) . L.
+  const float cax = (L.apos[0] - px) - 1.5f * (L.au[0] + L.av[0]), cay = (L.apos[1] - py) - 1.5f * (L.au[1] + L.av[1]),
+              caz = (L.apos[2] - pz) - 1.5f * (L.au[2] + L.av[2]);
+#endif
+#if RT_LIGHT_FAST & 2
+  const float nrx = -fmaf(2.0f * vdn, nx, dx), nry = -fmaf(2.0f * vdn, ny, dy), nrz = -fmaf(2.0f * vdn, nz, dz);
+#endif
   for (int base = 0; base < nrays; base += B) {
     float Lx[B], Ly[B], Lz[B], m[B];
     float mrf[REFR ? B : 1];   // REFR: the same verdicts for the REFRACTIVE spheres (m: the opaque ones)
@@ -897,6 +914,17 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     for (int k = 0; k < B; ++k) {
       const int j = base + k;
       float lx, ly, lz;
+#if RT_LIGHT_FAST & 1
+      if (j == 0) {  // scene['global_light'] (:198)
+        lx = L.ppos[0] - px; ly = L.ppos[1] - py; lz = L.ppos[2] - pz;
+      } else {       // area-light sample j-1 (:180-183)
+        float ru1, rv1;
+        draw_pair1<MODE>(level_key, uint32_t(j - 1), ru1, rv1);
+        lx = fmaf(L.av[0], rv1, fmaf(L.au[0], ru1, cax));
+        ly = fmaf(L.av[1], rv1, fmaf(L.au[1], ru1, cay));
+        lz = fmaf(L.av[2], rv1, fmaf(L.au[2], ru1, caz));
+      }
+#else
       if (j == 0) {  // scene['global_light'] (:198)
         lx = L.ppos[0]; ly = L.ppos[1]; lz = L.ppos[2];
       } else {       // area-light sample j-1 (:180-182)
@@ -908,6 +936,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         lz = fmaf(L.av[2], rv, fmaf(L.au[2], ru, L.apos[2]));
       }
       lx -= px; ly -= py; lz -= pz;                        // :183 / :198
+#endif
       // a ray beyond the light's sample count gets L = 0: it can never be shadowed and every
       // weight below (N.L, V.R) is then 0 too
       const float inv = (j < nrays) ? frsq(fmaf(lz, lz, fmaf(ly, ly, lx * lx))) : 0.0f;
@@ -1051,6 +1080,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         uint32_t cand = occl_row[word];
         uint32_t rel = 0u;
         while (__ballot(cand != 0u) != 0ull) {
+#if RT_CULL_STATS
+          g_dbg_turns += 1;
+#endif
           if (cand != 0u) {
             const int j = __ffs(int(cand)) - 1;
             cand &= cand - 1u;
@@ -1174,22 +1206,44 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     }
 #pragma unroll
     for (int k = 0; k < B; ++k) {
+#if RT_LIGHT_FAST & 2
+      // (one ray after the other — this ray's direction passes through the same statement as the sums of the rays before
+      // it: interleaved, the 13 power chains take registers that the kernel does not have)
+      asm volatile("" : "+v"(Lx[k]), "+v"(ad), "+v"(as));
+#endif
       const float ndl = fmaf(nz, Lz[k], fmaf(ny, Ly[k], nx * Lx[k]));
+#if RT_LIGHT_FAST & 2
+      // max(0, x) of a lit ray, 0 of a shadowed one, by sign bits (three full-rate ops; v_max and v_cndmask are
+      // half rate, and a select would bring a branch around the powers): x is kept iff neither x nor ~m is negative
+      const float vr = fmaf(nrz, Lz[k], fmaf(nry, Ly[k], nrx * Lx[k]));
+      const uint32_t shadowed = ~__float_as_uint(m[k]);                                   // sign set: blocked (:187 / :202)
+      auto lit_max0 = [&](float x) {
+        return __uint_as_float(__float_as_uint(x) & ~uint32_t(int32_t(__float_as_uint(x) | shadowed) >> 31));
+      };
+      const float wd = lit_max0(ndl);                                // :188 / :203
+      const float ws = pow50(lit_max0(vr));                          // :193 / :208  (0 ** 50 = 0)
+#else
       // view . (L - N*(2 L.N))  (:192-193 / :207-208; the sign of R is the reference's)
       const float vdl = -(fmaf(dz, Lz[k], fmaf(dy, Ly[k], dx * Lx[k])));
       const float vr = fmaf(-2.0f * ndl, vdn, vdl);
       const bool lit = int(__float_as_uint(m[k])) < 0;               // :187 / :202
       const float wd = lit ? fmaxf(0.f, ndl) : 0.f;                  // :188 / :203
       const float ws = lit ? pow50(fmaxf(0.f, vr)) : 0.f;            // :193 / :208
+#endif
       if (k == 0) {
         if (base == 0) { pd = wd; ps = ws; } else { ad += wd; as += ws; }
       } else { ad += wd; as += ws; }
     }
   }
 #if RT_CULL_STATS
-  dbg_flush(dbg_rel_, dbg_lanes_, dbg_iters_);
+  dbg_flush(dbg_rel_, dbg_lanes_, dbg_iters_, dbg_turns_);
 #endif
-  return LightSums{pd, ps, ad, as};
+#if RT_LIGHT_FAST & 2
+  return LightSums{pd, ps, ad, as, -nrx, -nry, -nrz};
+#else
+  const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));
+  return LightSums{pd, ps, ad, as, fmaf(-dn2, nx, dx), fmaf(-dn2, ny, dy), fmaf(-dn2, nz, dz)};
+#endif
 }
 
 // One shaded hit (trace_ray :240-258 without the recursion): hit point P on sphere `idx`, incoming
@@ -1234,8 +1288,7 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   ab = fmaf(tb * (m.z * keep), lb, ab);
   if (!(refl > 0.0f)) return false;                                  // :245
   tr *= refl * lr; tg *= refl * lg; tb *= refl * lb;
-  const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));      // :246
-  dx = fmaf(-dn2, nx, dx); dy = fmaf(-dn2, ny, dy); dz = fmaf(-dn2, nz, dz);
+  dx = w.rx; dy = w.ry; dz = w.rz;                                   // :246 (formed in lighting(): the same expression)
   ox = sx; oy = sy; oz = sz;                                         // :247
   return true;
 }
@@ -4065,7 +4118,7 @@ int rt_debug_counters(rt_ctx* ctx, uint64_t out[16]) {
   {  // culling statistics: [4] candidate spheres summed over lanes, [5] lane-chunks, [6] drain-loop turns summed over lanes
     unsigned long long h[4];
     RT_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h));
-    out[4] = h[0]; out[5] = h[1]; out[6] = h[2];
+    out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];   // [7] cull-loop turns summed over lanes
     unsigned long long z[4] = {0, 0, 0, 0};
     RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z));
   }

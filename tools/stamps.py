@@ -34,4 +34,4 @@ print(f"  {'other (setup/store)':20s} {100.0 * (tot - sum(a[8:14])) / max(tot, 1
 if not os.environ.get("RT_CULL_STATS"):
     print(f"passes: {a[4]}, records per pass {a[5] / max(a[4], 1):.2f} of 64, passes run short with tiles left: {100.0 * a[6] / max(a[4], 1):.2f} %")
     sys.exit(0)
-print(f"culling: {a[4] / max(a[5], 1):.2f} candidate spheres per lane and chunk, drain loop {a[6] / max(a[5], 1):.2f} turns per lane (= wave maximum)")
+print(f"culling: {a[4] / max(a[5], 1):.2f} surviving spheres per lane and chunk, cull loop {a[7] / max(a[5], 1):.2f} turns, drain loop {a[6] / max(a[5], 1):.2f} turns per lane (= wave maxima)")
