@@ -252,6 +252,17 @@ typedef const float4* cgeom_t;
 __device__ __forceinline__ cgeom_t as_const(const float4* p) { return p; }
 #endif
 
+// max(0, x) in ONE instruction: fmaxf() compiles to a second v_max that only quiets a signalling NaN (which cannot
+// occur here), and v_max is a half-rate instruction on gfx950
+__device__ __forceinline__ float max0(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return x > 0.f ? x : 0.f;
+#endif
+}
 __device__ __forceinline__ float pow50(float x) {  // `** 50` (raytracer.py:193,208), x >= 0
   float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16;
   return x32 * x16 * x2;
@@ -1227,8 +1238,8 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       const float vdl = -(fmaf(dz, Lz[k], fmaf(dy, Ly[k], dx * Lx[k])));
       const float vr = fmaf(-2.0f * ndl, vdn, vdl);
       const bool lit = int(__float_as_uint(m[k])) < 0;               // :187 / :202
-      const float wd = lit ? fmaxf(0.f, ndl) : 0.f;                  // :188 / :203
-      const float ws = lit ? pow50(fmaxf(0.f, vr)) : 0.f;            // :193 / :208
+      const float wd = lit ? max0(ndl) : 0.f;                        // :188 / :203
+      const float ws = lit ? pow50(max0(vr)) : 0.f;                  // :193 / :208
 #endif
       if (k == 0) {
         if (base == 0) { pd = wd; ps = ws; } else { ad += wd; as += ws; }
