@@ -55,6 +55,10 @@
 #define RT_LIGHT_FAST 1   // lighting(), bit 0 (on): light positions relative to P formed once per point (+1.2 %); bit 1 (off: measured -3 %, the
                           // kernel then spills 10 VGPRs around the shadow loops): mirrored view vector and sign-bit selects in the shading
 #endif
+#ifndef RT_SHADE_MASK
+#define RT_SHADE_MASK 0   // 1: light weights selected by sign-bit masks, no branch around the powers — 20 straight-line instructions per
+                          // ray instead of 22 + 6 scalar, no extra spill, and measured 2.7 % SLOWER on config 2 and the target
+#endif
 #ifndef RT_GEOM_SRC
 #define RT_GEOM_SRC 0     // shadow scan reads spheres from: 0 LDS, 1 LDS prefetched, 2 scalar loads
 #endif
@@ -69,6 +73,7 @@ struct DevLights {
   float apos[3], au[3], av[3], acol[3], aint;
   int ns;
   float arad;   // 0.5 (|au| + |av|): every area-light sample lies within this distance of apos
+  float inv_ns; // RN(1 / ns): what `1.0f / float(ns)` gives, formed once on the host instead of per shaded hit (10 instructions)
 };
 
 // frames per launch: the fixed cost of a launch pair (ramp-up, the stream kernel's uneven tail, the
@@ -884,7 +889,7 @@ __device__ __forceinline__ void light_colour(const DevLights& L, const LightSums
   float ps = w.ps, as = w.as;
   if (!(spec > 0.0f)) { ps = 0.f; as = 0.f; }                        // :191 / :206
   // :204 + :209 + :189/:194/:196
-  const float inv_ns = 1.0f / float(L.ns);
+  const float inv_ns = L.inv_ns;
   const float pk = L.pint * w.pd, psk = L.pint * spec * ps;
   const float ak = L.aint * w.ad * inv_ns, ask = L.aint * spec * as * inv_ns;
   lr = fmaf(mr * L.pcol[0], pk, L.pcol[0] * psk) + L.acol[0] * (ak + ask);
@@ -1238,8 +1243,16 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       const float vdl = -(fmaf(dz, Lz[k], fmaf(dy, Ly[k], dx * Lx[k])));
       const float vr = fmaf(-2.0f * ndl, vdn, vdl);
       const bool lit = int(__float_as_uint(m[k])) < 0;               // :187 / :202
+#if RT_SHADE_MASK
+      // (lit or not by the verdict's sign bit as a mask: no select, no branch around the seven multiplies)
+      const uint32_t litmask = uint32_t(int32_t(__float_as_uint(m[k])) >> 31);
+      const float wd = __uint_as_float(__float_as_uint(max0(ndl)) & litmask);              // :188 / :203
+      const float ws = __uint_as_float(__float_as_uint(pow50(max0(vr))) & litmask);        // :193 / :208
+      (void)lit;
+#else
       const float wd = lit ? max0(ndl) : 0.f;                        // :188 / :203
       const float ws = lit ? pow50(max0(vr)) : 0.f;                  // :193 / :208
+#endif
 #endif
       if (k == 0) {
         if (base == 0) { pd = wd; ps = ws; } else { ad += wd; as += ws; }
@@ -3733,7 +3746,7 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   L.pint = lights->point_intensity;
   memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
   memcpy(L.acol, lights->area_color, 12);
-  L.aint = lights->area_intensity; L.ns = lights->area_samples;
+  L.aint = lights->area_intensity; L.ns = lights->area_samples; L.inv_ns = 1.0f / float(L.ns);
   L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
                    std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
   if (n_spheres > 0) {
