@@ -194,7 +194,7 @@ constexpr int kVisTiles = RT_VIS_TILES;
 #define RT_VIS_SKIP 1      // the visibility pass culls per wave at any sphere count: blocks that no sphere reaches build no rays
 #endif
 #ifndef RT_VIS_CULL_FROM
-#define RT_VIS_CULL_FROM 16   // scenes with more spheres than this: the visibility pass culls per wave (primary_hit_culled)
+#define RT_VIS_CULL_FROM 4    // scenes with more spheres than this: a block tests only the table groups that hold a sphere its cone reaches (primary_hit_culled; 16 -> 4: +0.9 % on config 2)
 #endif
 constexpr int kVisCullFrom = RT_VIS_CULL_FROM;
 constexpr int kBlock = 256;        // 4 waves
