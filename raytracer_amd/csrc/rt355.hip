@@ -55,6 +55,9 @@
 #define RT_LIGHT_FAST 1   // lighting(), bit 0 (on): light positions relative to P formed once per point (+1.2 %); bit 1 (off: measured -3 %, the
                           // kernel then spills 10 VGPRs around the shadow loops): mirrored view vector and sign-bit selects in the shading
 #endif
+#ifndef RT_INTAKE_FALLTHROUGH
+#define RT_INTAKE_FALLTHROUGH 1
+#endif
 #ifndef RT_SHADE_MASK
 #define RT_SHADE_MASK 0   // 1: light weights selected by sign-bit masks, no branch around the powers — 20 straight-line instructions per
                           // ray instead of 22 + 6 scalar, no extra spill, and measured 2.7 % SLOWER on config 2 and the target
@@ -2246,9 +2249,20 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
       }
       wave_lds_fence();
       st_fetch += RT_NOW() - s0;
+#if !RT_INTAKE_FALLTHROUGH
       continue;
+#endif
+      // (straight on into the pass: the intake ends only with a pass's worth of records, without a free slot, or with
+      // nothing left anywhere — going round the loop first came to the same decisions through ~130 instructions of
+      // scalar-register spill traffic at the loop head)
     }
-    if (n_bounce == 0) break;
+    if (n_bounce == 0) {
+      // (an intake may have left nothing to shade but a slot whose first sample was empty: its next sample comes in at
+      // the top of the loop; likewise a block that a refractive wave has set aside)
+      if (MULTI && slot_ready != 0u) continue;
+      if (REFR && sp_blocks > 0) continue;
+      break;
+    }
 
     // ------------------------------ shading pass -----------------------------------------
     {
