@@ -48,9 +48,9 @@ PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 
 # (TCC_EA0_WRREQ x 64 + TCC_EA0_RDREQ x 64 x 2, the guide's gfx950 correction), and the rays of that launch pair.
 # (tools/pmc_constants.py prints these lines from a tools/profile.sh directory.)
 PMC = {
-    "c2": dict(profile="profiles/r2s_c2_rt_{stream,visibility}_kernel.txt", flops=4.294e+11, valu=9.756e+09, salu=3.502e+09, hbm_bytes=1.207e+10, rays=7.863e+09),
-    "t64": dict(profile="profiles/r2s_t64_rt_{stream,visibility}_kernel.txt", flops=3.694e+11, valu=8.501e+09, salu=3.139e+09, hbm_bytes=1.278e+10, rays=6.428e+09),
-    "c4": dict(profile="profiles/r2s_c4_rt_{stream,visibility}_kernel.txt", flops=4.015e+11, valu=7.812e+09, salu=2.35e+09, hbm_bytes=9.551e+09, rays=3.36e+09),
+    "c2": dict(profile="profiles/r2x_c2_rt_{stream,visibility}_kernel.txt", flops=3.956e+11, valu=8.537e+09, salu=3.348e+09, hbm_bytes=1.187e+10, rays=7.863e+09),
+    "t64": dict(profile="profiles/r2x_t64_rt_{stream,visibility}_kernel.txt", flops=3.483e+11, valu=7.665e+09, salu=3.009e+09, hbm_bytes=1.269e+10, rays=6.428e+09),
+    "c4": dict(profile="profiles/r2x_c4_rt_{stream,visibility}_kernel.txt", flops=3.877e+11, valu=7.309e+09, salu=2.286e+09, hbm_bytes=1.008e+10, rays=3.36e+09),
 }
 
 WORKLOADS = {
