@@ -918,8 +918,10 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
   // Per point, not per ray: the area light's corner seen from P — sample j is  A + u (r_u - 0.5) + v (r_v - 0.5) - P
   // = (A - P - 1.5 (u + v)) + u (1 + r_u) + v (1 + r_v), and the draws come as 1 + r — and the mirrored view vector:
   // view . (L - N (2 L.N))  (:192-193 / :207-208) = -(D - 2 (D.N) N) . L.
-  const float cax = (L.apos[0] - px) - 1.5f * (L.au[0] + L.av[0]), cay = (L.apos[1] - py) - 1.5f * (L.au[1] + L.av[1]),
-              caz = (L.apos[2] - pz) - 1.5f * (L.au[2] + L.av[2]);
+  // (explicit fused multiply-adds: left to the compiler, `a - 1.5 b` is contracted in one inlining context and not in
+  // another, and the stream and pixel kernels then differ in a last bit somewhere — found by tools/fuzz_culls.py)
+  const float cax = fmaf(-1.5f, L.au[0] + L.av[0], L.apos[0] - px), cay = fmaf(-1.5f, L.au[1] + L.av[1], L.apos[1] - py),
+              caz = fmaf(-1.5f, L.au[2] + L.av[2], L.apos[2] - pz);
 #endif
 #if RT_LIGHT_FAST & 2
   const float nrx = -fmaf(2.0f * vdn, nx, dx), nry = -fmaf(2.0f * vdn, ny, dy), nrz = -fmaf(2.0f * vdn, nz, dz);
