@@ -152,6 +152,8 @@ struct RenderParams {
   const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
   int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
+  int defer_sparse;      // ... and only for the tiles the visibility pass marked occupied (one sample per pixel, 8-bit frames): that
+                         // pass clears their pixel sums and writes the black of every other tile itself; rt_resolve_tiles_kernel
   int tile_flush;        // the stream kernel stores every occupied tile whole (its SLOTS variant): the visibility pass
                          // writes the pixels of empty tiles only
   long long vis_sample_stride;  // all samples shaded by one stream-kernel launch (the kernels' MULTI variants): elements
@@ -1523,7 +1525,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
   // The common case: a whole block of an 8-bit frame with dword-aligned rows, one sample per pixel, nothing else
   // asked for.  Every pixel this kernel writes is then black (misses are final, hits get a placeholder), which
   // the short forms of the epilogue below rely on.
-  const bool simple = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && rows == 8 &&
+  const bool simple = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && (!p.defer_output || p.defer_sparse) && p.out_rgb && rows == 8 &&
                       cols[NT - 1] == 8 && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
                       (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
   // The wave culls the spheres against the bounding cone of its rays first (primary_hit_culled): with many
@@ -1555,7 +1557,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
 #endif
     // (nothing to write at all: a sample before the last of the MULTI path leaves only records and `present` bits
     // of tiles it hit; on the deferred-output path — refractive scenes — every pixel comes from rt_resolve_kernel)
-    if (!need_rays && !p.out_hit && (MULTI ? !last_sample : p.defer_output != 0)) return;
+    if (!need_rays && !p.out_hit && (MULTI ? !last_sample : (p.defer_output != 0 && !p.defer_sparse))) return;
     if constexpr (!MULTI) {
       // The common case of such a block — whole, one sample per pixel, 8-bit frame only, dword-aligned rows —
       // leaves at once: its rows are NT x 24 contiguous bytes of black, 12 per lane with NT = 4 (one store
@@ -1625,7 +1627,11 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
               atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));
             }
           }
-          if (!(occupied && p.tile_flush) && lane < 48) *reinterpret_cast<uint32_t*>(o + q * 24) = 0u;
+          if (occupied && p.defer_sparse) {   // the tile's pixel sums start at zero (the stream kernel adds tree nodes into them)
+            float* a = p.accum + (accum_px + wpix0 + 8 * q) * 3;
+            a[0] = 0.f; a[1] = 0.f; a[2] = 0.f;
+          }
+          if (!(occupied && (p.tile_flush || p.defer_sparse)) && lane < 48) *reinterpret_cast<uint32_t*>(o + q * 24) = 0u;
         }
         return;
       }
@@ -1644,7 +1650,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
   // ... and a header names the tile, so a record is self-describing for whoever loads it
   int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tile_pitch + (col0 >> 3)) * kVisTile;
   uint8_t* out = p.out_rgb + frame_px * 3;
-  const bool write_rgb = p.out_rgb && last_sample && !p.defer_output;
+  const bool write_rgb = p.out_rgb && last_sample && (!p.defer_output || p.defer_sparse);
   const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
   const uint32_t id0 = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
                        uint32_t(col0 >> 3);               // tile id of the wave's first tile; the others follow
@@ -1694,7 +1700,12 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
       atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
     }
     // (tile_flush: the stream kernel stores an occupied tile whole, its black pixels included)
-    if (write_rgb && !(occupied && p.tile_flush))
+    if constexpr (!MULTI)
+      if (occupied && p.defer_sparse && live[q]) {
+        float* a = p.accum + (accum_px + wpix0 + 8 * q) * 3;
+        a[0] = 0.f; a[1] = 0.f; a[2] = 0.f;
+      }
+    if (write_rgb && !(occupied && (p.tile_flush || p.defer_sparse)))
       store_tile8(out, p.nx, row0, col0 + 8 * q, rows, cols[q], lane, rgbx[q], dwords);
   }
 }
@@ -1718,10 +1729,10 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   if constexpr (RT_VIS_SKIP && !CUBES && kVisRows > 1) {
     const long long frame_px = (long long)frame * p.frame_stride_px;
     const bool whole = rowR + 8 * kVisRows <= p.n_rows && p.nx - col0 >= 8 * NT;
-    const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : p.defer_output != 0);
+    const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : (p.defer_output != 0 && !p.defer_sparse));
     // (MULTI: the launch of the last sample writes the black of tiles that NO sample hit — `present` knows)
     const bool black_owed = (MULTI ? p.sample_index + 1 == p.n_samples : p.n_samples == 1) && !p.out_f32 && !p.out_hit &&
-                            !p.defer_output && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
+                            (!p.defer_output || p.defer_sparse) && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
                             (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
     if ((nothing_owed || black_owed) && p.n_spheres <= 64) {
       bool any = false;
@@ -2884,6 +2895,38 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(const RenderParams p) {
   }
 }
 
+// The same for the tiles the visibility pass marked occupied only (RenderParams::defer_sparse: refractive scenes at one
+// sample per pixel, 8-bit frames): every other tile is black already, and only these tiles' sums were ever cleared or
+// added to — on a mostly empty frame a fifth of the 12 + 3 bytes per pixel that clearing and resolving everything moves.
+// One wave per four tiles side by side, as in the visibility pass; whole tiles leave as dwords (store_tile8).
+__global__ __launch_bounds__(256) void rt_resolve_tiles_kernel(const RenderParams p) {
+  constexpr int NT = kVisTiles;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.z;
+  const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), row0 = int(blockIdx.x) * 8;
+  if (p.nx - col0 <= 0) return;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int rows = min(8, p.n_rows - row0);
+  const long long frame_px = (long long)frame * p.frame_stride_px, accum_px = (long long)frame * p.accum_stride_px;
+  uint8_t* out = p.out_rgb + frame_px * 3;
+  const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+  const uint32_t id0 = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
+                       uint32_t(col0 >> 3);
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int cols = min(8, p.nx - col0 - 8 * q);
+    if (cols <= 0) break;
+    const uint32_t id = id0 + uint32_t(q), slot = id / kTileCounters, h = id % kTileCounters;
+    if (!((p.occ[size_t(h) * size_t(p.occ_words) + (slot >> 5)] >> (slot & 31u)) & 1u)) continue;   // wave-uniform
+    uint32_t rgbx = 0u;
+    if (lx < cols && ly < rows) {
+      const float* a = p.accum + (accum_px + (long long)(row0 + ly) * p.nx + (col0 + 8 * q + lx)) * 3;
+      rgbx = pack_rgbx(a[0] * p.inv_samples, a[1] * p.inv_samples, a[2] * p.inv_samples);
+    }
+    store_tile8(out, p.nx, row0, col0 + 8 * q, rows, cols, lane, rgbx, dwords);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: context + C ABI
 // ------------------------------------------------------------------------------------------
@@ -3412,6 +3455,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];
   }
   p.defer_output = refr ? 1 : 0;
+  p.defer_sparse = (refr && stream_kernel && samples == 1 && out_rgb && !out_f32) ? 1 : 0;
   p.tile_flush = slots ? 1 : 0;
   p.accum = ctx->d_accum;
   p.spill = ctx->d_spill; p.spill_blocks = spill_blocks;
@@ -3516,8 +3560,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         RT_HIP(ctx, hipGetLastError());
       }
     }
-    if (refr)   // every node of every sample adds into the pixel sums
-      RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));
+    if (refr && !p.defer_sparse)   // every node of every sample adds into the pixel sums (defer_sparse: the visibility pass
+      RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));   // clears those of occupied tiles)
     if (multi)   // which samples of a tile hit anything: collected by the visibility launches below
       RT_HIP(ctx, hipMemsetAsync(ctx->d_present, 0, (size_t(frame_tiles) * size_t(nf) + 8) * sizeof(unsigned long long), ctx->stream));
     for (int s = 0; s < samples; ++s) {
@@ -3539,9 +3583,14 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples)
           hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0 || p.list_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
-        if (refr && s + 1 == samples)   // (never MULTI)
-          hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
-                             ctx->stream, p);
+        if (refr && s + 1 == samples) {   // (never MULTI)
+          if (p.defer_sparse)
+            hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf)),
+                               dim3(256), 0, ctx->stream, p);
+          else
+            hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
+                               ctx->stream, p);
+        }
       } else {
         if (rng_mode == RT_RNG_KEYED)
           hipLaunchKernelGGL(rt_pixel_kernel<RT_RNG_KEYED>, grid, dim3(kBlock), lds, ctx->stream, p);
