@@ -776,6 +776,15 @@ __device__ __forceinline__ bool sphere_in_cone(const float4 s, const RayCone& co
   const float rhs = fmaf(along, cone.sin_t, fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f)));
   return rhs >= 0.0f && rhs * rhs >= perp2 * cone.cos2_t;
 }
+// Can a ray of the cone "hit" the box?  intersect_cube accepts a box that the ray's LINE crosses, also behind the origin
+// (cube_t: t < 0 counts), so the box is tested against the cone and its mirror image, through its bounding sphere.
+__device__ __forceinline__ bool box_in_double_cone(const float4 lo, const float4 hi, const RayCone& cone, float ox, float oy,
+                                                   float oz) {
+  const float hx = 0.5f * (hi.x - lo.x), hy = 0.5f * (hi.y - lo.y), hz = 0.5f * (hi.z - lo.z);
+  const float4 s = make_float4(lo.x + hx, lo.y + hy, lo.z + hz, fmaf(hz, hz, fmaf(hy, hy, hx * hx)) * 1.0001f);
+  const RayCone back{-cone.ax, -cone.ay, -cone.az, cone.sin_t, cone.cos2_t};
+  return sphere_in_cone(s, cone, ox, oy, oz) || sphere_in_cone(s, back, ox, oy, oz);
+}
 // (`first` = the ballot of sphere_in_cone over spheres 0..63, which the caller has taken already)
 template <int NP>
 __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
@@ -1553,7 +1562,16 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
     #if defined(RT_EXP_VIS_NORAYS)
     const bool need_rays = false;   // timing experiment only: the pass's floor (cone, cull, black pixels)
 #else
-    const bool need_rays = !RT_VIS_SKIP || CUBES || first != 0ull || p.n_spheres > 64;
+    bool cube_reach = false;
+    if constexpr (CUBES) {   // (one cube per lane; beyond 64 cubes, or without a cone — no spheres at all —, every ray is built)
+      cube_reach = true;
+      if (cull && p.n_cubes <= 64) {
+        const int c = lane < p.n_cubes ? lane : p.n_cubes - 1;
+        cube_reach = __ballot(lane < p.n_cubes && box_in_double_cone(p.cubes[2 * c], p.cubes[2 * c + 1], cone, cam.origin[0],
+                                                                     cam.origin[1], cam.origin[2])) != 0ull;
+      }
+    }
+    const bool need_rays = !RT_VIS_SKIP || cube_reach || first != 0ull || p.n_spheres > 64;
 #endif
     // (nothing to write at all: a sample before the last of the MULTI path leaves only records and `present` bits
     // of tiles it hit; on the deferred-output path — refractive scenes — every pixel comes from rt_resolve_kernel)
@@ -1726,7 +1744,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
   const int frame = blockIdx.z;
   const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * kVisRows);   // window coordinates
   if (p.nx - col0 <= 0) return;                           // wave-uniform: beyond the right edge
-  if constexpr (RT_VIS_SKIP && !CUBES && kVisRows > 1) {
+  if constexpr (RT_VIS_SKIP && kVisRows > 1) {
     const long long frame_px = (long long)frame * p.frame_stride_px;
     const bool whole = rowR + 8 * kVisRows <= p.n_rows && p.nx - col0 >= 8 * NT;
     const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : (p.defer_output != 0 && !p.defer_sparse));
@@ -1734,7 +1752,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     const bool black_owed = (MULTI ? p.sample_index + 1 == p.n_samples : p.n_samples == 1) && !p.out_f32 && !p.out_hit &&
                             (!p.defer_output || p.defer_sparse) && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
                             (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
-    if ((nothing_owed || black_owed) && p.n_spheres <= 64) {
+    if ((nothing_owed || black_owed) && p.n_spheres <= 64 && (!CUBES || (p.n_spheres > 0 && p.n_cubes <= 64))) {
       bool any = false;
       if (p.n_spheres > 0) {
         const float4 sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
@@ -1744,6 +1762,11 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
         const int yb = (p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + last : row_of(p, last)) + 1;
         const RayCone cone = bundle_cone(p, fr.cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
         any = __ballot(lane < p.n_spheres && sphere_in_cone(sphere, cone, fr.cam.origin[0], fr.cam.origin[1], fr.cam.origin[2])) != 0ull;
+        if constexpr (CUBES) {
+          const int c = lane < p.n_cubes ? lane : p.n_cubes - 1;
+          any = any || __ballot(lane < p.n_cubes && box_in_double_cone(p.cubes[2 * c], p.cubes[2 * c + 1], cone, fr.cam.origin[0],
+                                                                       fr.cam.origin[1], fr.cam.origin[2])) != 0ull;
+        }
       }
       if constexpr (MULTI) {
         if (!any && black_owed) {   // did an earlier sample hit a tile of the region?  (lane l: tile l % NT of block l / NT)
