@@ -276,6 +276,32 @@ def test_random_lights_and_cameras_against_oracle(renderer, oracle, case):
     check_rgb(img.cpu().numpy(), o["rgb8"])
 
 
+@pytest.mark.parametrize("where", ["behind", "beside", "around"])
+def test_cubes_behind_and_around_the_camera(renderer, oracle, where):
+    """intersect_cube (:106-137) accepts a box that a ray's LINE crosses behind the origin (t < 0 beats every sphere,
+    :162), so the visibility pass must not cull a box by the forward cone of a block alone: a box behind the camera
+    (hit through the mirror image of the pixels it would cover), one beside it that no primary ray or its line
+    reaches (culled: the spheres show), and one that contains the camera — frames and hit maps against the oracle,
+    at a size with whole regions, whole blocks and ragged edges."""
+    sc = default_scene()
+    m = Material(Vector3(0.9, 0.6, 0.2), specular=0.5, reflection=0.3)
+    box = {"behind": (Vector3(-0.4, -0.3, 2.0), Vector3(0.5, 0.4, 3.0)),
+           "beside": (Vector3(6.0, -0.5, -0.5), Vector3(7.0, 0.5, 0.5)),
+           "around": (Vector3(-1.5, -1.2, -1.0), Vector3(1.2, 1.5, 1.3))}[where]
+    sc["spheres"] = list(sc["spheres"]) + [Cube(box[0], box[1], m)]
+    w, h = 328, 203
+    renderer.upload_scene(sc)
+    img, hit = renderer.render(w, h, 1, max_depth=3, rng_mode="K", seed=2, return_hit_index=True)
+    plain = renderer.render(w, h, 1, max_depth=3, rng_mode="K", seed=2)      # (no hit map asked for: the short forms of the pass)
+    assert bool((plain == img).all())
+    o = oracle.render_scene(sc, w, h, samples=1, max_depth=3, mode="K", seed=2)
+    check_cube_hits(hit.cpu().numpy(), o)
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+    cube_index = len(sc["spheres"]) - 1
+    n_cube = int((o["hit"] == cube_index).sum())
+    assert (n_cube > 1000) if where != "beside" else (n_cube == 0)
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_random_glass_and_cubes_against_oracle(renderer, oracle, case):
     """Random mixes of opaque / glass spheres and small cubes (the REFR and CUBES kernel variants, the
