@@ -1190,20 +1190,63 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #pragma unroll 2
     for (int i = 0; i < n; ++i) test_sphere(sg[i]);
 #endif
-    if constexpr (CUBES && !REFR) {
+    if constexpr (CUBES) {
       // any-hit over the cubes: the ray is blocked if intersect_cube gives a non-zero t of EITHER sign
-      // (:137, :162 — see cube_t), so every cube is tested for every ray, ray by ray (three reciprocals
-      // per ray, shared by all cubes)
-#pragma unroll
-      for (int k = 0; k < B; ++k) {
-        const float ix = frcp(Lx[k]), iy = frcp(Ly[k]), iz = frcp(Lz[k]);
-        bool hit = false;
-        for (int c = 0; c < nc; ++c) {
-          float t;
-          int face;
-          hit = hit || cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], sx, sy, sz, Lx[k], Ly[k], Lz[k], ix, iy, iz, t, face);
+      // (:137, :162 — see cube_t): the ray's LINE decides.  Per lane, the cubes whose bounding sphere reaches into the
+      // cone of the area light's rays or its mirror image (apex S; the test of the sphere cull with |along|), or — first
+      // batch — comes within reach of the point-light ray's line, are collected in a mask (32 cubes at a time); the
+      // rays are then tested, ray by ray (three reciprocals per ray), against the lane's own candidates only: the wave
+      // loops max-over-lanes(candidates) times per ray instead of once per cube.
+      const float ax0 = L.apos[0] - px, ay0 = L.apos[1] - py, az0 = L.apos[2] - pz;
+      const float inv_dA = frsq(fmaf(az0, az0, fmaf(ay0, ay0, ax0 * ax0)));
+      const float axx = ax0 * inv_dA, axy = ay0 * inv_dA, axz = az0 * inv_dA;
+      const float sin_t = fminf(1.0f, L.arad * inv_dA * 1.00390625f);
+      const float cos2_t = fmaf(-sin_t, sin_t, 1.0f);
+      const bool wide = !(sin_t < 0.99f);
+      for (int c0 = 0; c0 < nc; c0 += 32) {
+        uint32_t cm = 0u;
+        const int cn = min(32, nc - c0);
+        for (int c = 0; c < cn; ++c) {
+          const float4 lo = sg[n + 2 * (c0 + c)], hi = sg[n + 2 * (c0 + c) + 1];      // wave-uniform: LDS broadcast
+          const float hx = 0.5f * (hi.x - lo.x), hy = 0.5f * (hi.y - lo.y), hz = 0.5f * (hi.z - lo.z);
+          const float cx = (lo.x + hx) - sx, cy = (lo.y + hy) - sy, cz = (lo.z + hz) - sz;
+          const float d2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
+          const float r = fsqrt(fmaf(hz, hz, fmaf(hy, hy, hx * hx)));
+          const float reach = fmaf(r, 1.00390625f, fmaf(d2, 1.0f / 65536.0f, 1.0f / 1048576.0f));
+          const float along = fmaf(cz, axz, fmaf(cy, axy, cx * axx));
+          const float perp2 = fmaxf(0.0f, fmaf(-along, along, d2));
+          const float rhs = fmaf(fabsf(along), sin_t, reach);
+          bool cand = wide || rhs * rhs >= perp2 * cos2_t;
+          if (base == 0) {                                         // the point-light ray: distance of its line from the centre
+            const float al0 = fmaf(cz, Lz[0], fmaf(cy, Ly[0], cx * Lx[0]));
+            cand = cand || fmaf(-al0, al0, d2) <= reach * reach;
+          }
+          cm |= (cand ? 1u : 0u) << c;
         }
-        if (hit) m[k] = 0.0f;
+        while (__ballot(cm != 0u) != 0ull) {
+          if (cm != 0u) {
+            const int c = c0 + __ffs(int(cm)) - 1;
+            cm &= cm - 1u;
+            const float4 lo = sg[n + 2 * c], hi = sg[n + 2 * c + 1];
+            bool glass_cube = false;
+            if constexpr (REFR) glass_cube = refr[n + c].x > 0.0f;
+            (void)glass_cube;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+              float t;
+              int face;
+              float lx = Lx[k], ly = Ly[k], lz = Lz[k];
+              asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz));     // keeps the 39 reciprocals inside the loop (registers)
+              if (cube_t(lo, hi, sx, sy, sz, lx, ly, lz, frcp(lx), frcp(ly), frcp(lz), t, face)) {
+                if constexpr (REFR) {                              // (which kind of hit: see below)
+                  if (glass_cube) mrf[k] = 0.0f; else m[k] = 0.0f;
+                } else {
+                  m[k] = 0.0f;
+                }
+              }
+            }
+          }
+        }
       }
     }
     if constexpr (REFR) {
@@ -1212,20 +1255,10 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       // whether it hits SOME refractive one (mrf) — the any-hit tests of the opaque path, over the same culled
       // candidates, no root taken.  No opaque hit: lit.  Opaque hits only: blocked.  Both (a ray through glass
       // towards something solid, or the other way round: rare): the nearest hit decides, found by the full scan
-      // of find_nearest_intersection for that ray.  Cubes (their line rule, :137, :162) are tested ray by ray.
+      // of find_nearest_intersection for that ray.  Cubes (their line rule, :137, :162) have been entered into m and mrf above.
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         bool solid = int(__float_as_uint(m[k])) >= 0, glass = int(__float_as_uint(mrf[k])) >= 0;
-        if constexpr (CUBES) {
-          const float ix = frcp(Lx[k]), iy = frcp(Ly[k]), iz = frcp(Lz[k]);
-          for (int c = 0; c < nc; ++c) {
-            float t;
-            int face;
-            if (cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], sx, sy, sz, Lx[k], Ly[k], Lz[k], ix, iy, iz, t, face)) {
-              if (refr[n + c].x > 0.0f) glass = true; else solid = true;
-            }
-          }
-        }
         bool blocked = solid && !glass;
         if (solid && glass && base + k < nrays) {
           float t;

@@ -302,6 +302,43 @@ def test_cubes_behind_and_around_the_camera(renderer, oracle, where):
     assert (n_cube > 1000) if where != "beside" else (n_cube == 0)
 
 
+@pytest.mark.parametrize("glass", [False, True])
+def test_cube_shadows_follow_the_line_rule(renderer, oracle, glass):
+    """Shadow rays and cubes: intersect_cube (:106-137) blocks a shadow ray whose LINE crosses the box on either side
+    of the shaded point (:162, :187/:202), so lighting() collects, per lane, the boxes that reach into the cone of the
+    light's rays or its mirror image.  Boxes between the spheres and the lights, beyond the lights, below the spheres
+    on the far side of the light lines, and well off every line (culled) — opaque and, second case, with a refractive
+    box and a refractive sphere (the nearest-hit rule of :187) — against the oracle."""
+    sc = default_scene()
+    m = Material(Vector3(0.3, 0.7, 0.4), specular=0.4, reflection=0.2)
+    g = Material(Vector3(0.9, 0.9, 1.0), specular=0.6, reflection=0.1)
+    if glass:
+        g.refraction, g.refractive_index = 0.8, 1.33
+        sc["spheres"][1].material.refraction, sc["spheres"][1].material.refractive_index = 0.6, 1.5
+    lp, ap = sc["global_light"].position, sc["area_light"].position
+    def box(c, h, mat):
+        return Cube(Vector3(c[0] - h, c[1] - h, c[2] - h), Vector3(c[0] + h, c[1] + h, c[2] + h), mat)
+    target = sc["spheres"][0].center
+    def along(light, f):
+        return (target.x + f * (light.x - target.x), target.y + f * (light.y - target.y), target.z + f * (light.z - target.z))
+    sc["spheres"] = list(sc["spheres"]) + [
+        box(along(lp, 0.6), 0.25, m),          # between the first sphere and the point light
+        box(along(ap, 1.4), 0.4, g),           # beyond the area light, on its line
+        box(along(lp, -0.8), 0.5, m),          # on the far side of the sphere from the light (t < 0 on the line)
+        box((30.0, 25.0, 10.0), 0.5, m),       # off every line
+    ]
+    w, h = 320, 180
+    renderer.upload_scene(sc)
+    img, hit = renderer.render(w, h, 1, max_depth=3, rng_mode="K", seed=4, return_hit_index=True)
+    o = oracle.render_scene(sc, w, h, samples=1, max_depth=3, mode="K", seed=4)
+    check_cube_hits(hit.cpu().numpy(), o)
+    check_rgb(img.cpu().numpy(), o["rgb8"])
+    sc2 = dict(sc)
+    sc2["spheres"] = sc["spheres"][:-4] + sc["spheres"][-1:]
+    o2 = oracle.render_scene(sc2, w, h, samples=1, max_depth=3, mode="K", seed=4)
+    assert (o2["rgb8"].astype(int) != o["rgb8"].astype(int)).any(1).mean() > 0.02      # (the boxes do cast shadows)
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_random_glass_and_cubes_against_oracle(renderer, oracle, case):
     """Random mixes of opaque / glass spheres and small cubes (the REFR and CUBES kernel variants, the
