@@ -51,6 +51,9 @@
 #ifndef RT_SHADOW_CHEAP
 #define RT_SHADOW_CHEAP 1 // shadow scan: plain discriminant + exact fallback in the ambiguous band
 #endif
+#ifndef RT_CUBE_SHADOW_CULL
+#define RT_CUBE_SHADOW_CULL 1   // lighting(): per-lane candidate boxes for the shadow rays (0: all boxes, for fuzzing)
+#endif
 #ifndef RT_LIGHT_FAST
 #define RT_LIGHT_FAST 1   // lighting(), bit 0 (on): light positions relative to P formed once per point (+1.2 %); bit 1 (off: measured -3 %, the
                           // kernel then spills 10 VGPRs around the shadow loops): mirrored view vector and sign-bit selects in the shading
@@ -1223,6 +1226,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
           }
           cm |= (cand ? 1u : 0u) << c;
         }
+#if !RT_CUBE_SHADOW_CULL
+        cm = cn >= 32 ? ~0u : (1u << cn) - 1u;      // (diagnostic build: every box for every lane — tools/fuzz_cubes.py)
+#endif
         while (__ballot(cm != 0u) != 0ull) {
           if (cm != 0u) {
             const int c = c0 + __ffs(int(cm)) - 1;
@@ -2056,8 +2062,8 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
   const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kBlock / 64) + wave);
   const int n_waves = int(gridDim.x) * (kBlock / 64);
   uint32_t n_trace = 0, n_shade = 0;
-  unsigned long long st_fetch = 0, st_pop = 0, st_light = 0, st_near = 0;
-  const unsigned long long st_begin = RT_NOW();
+  [[maybe_unused]] unsigned long long st_fetch = 0, st_pop = 0, st_light = 0, st_near = 0;     // (read in RT_STAMPS builds only)
+  [[maybe_unused]] const unsigned long long st_begin = RT_NOW();
   int n_bounce = 0;               // wave-uniform queue length
   bool done = false;              // no tile is left for this wave
 
@@ -2092,8 +2098,8 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
   // ---- ring of tiles whose index data is in LDS or on its way (FIFO: head = next to consume)
   uint32_t head = 0, tail = 0;     // tile counts
   bool supply_done = false;
-  unsigned long long st_topup = 0, st_wait = 0;
-  unsigned st_passes = 0, st_lanes = 0, st_starved = 0;
+  [[maybe_unused]] unsigned long long st_topup = 0, st_wait = 0;
+  [[maybe_unused]] unsigned st_passes = 0, st_lanes = 0, st_starved = 0;
 
   // ---- REFR: records set aside in global memory (see the pass sizing below), a stack of 64-record blocks
   int sp_blocks = 0;
