@@ -1908,15 +1908,18 @@ static_assert(kTileSlots >= 2 && kTileSlots <= 8, "slot | pixel takes 9 bits of 
 // tile's samples in LDS as three floats per pixel and takes them ONE AFTER ANOTHER, in sample order — the sum
 // is the one the per-sample launches form in `accum`, to the last bit — while other slots keep the passes full.
 // It holds the tile record of its next sample (prefetched) besides.
+#ifndef RT_TILE_SLOTS_MULTI_SMALL
+#define RT_TILE_SLOTS_MULTI_SMALL 3   // OUT = 3: few enough slots (and one ring entry) for FOUR workgroups per CU on scenes of up to 36 spheres
+#endif
 #ifndef RT_TILE_SLOTS_MULTI
 #define RT_TILE_SLOTS_MULTI 6
 #endif
 constexpr int kTileSlotsMulti = RT_TILE_SLOTS_MULTI;
 static_assert(kTileSlotsMulti >= 2 && kTileSlotsMulti <= 8, "slot | pixel takes 9 bits of a record's meta word");
 constexpr int kSlotHdr = 4;                                 // words: tx | ty << 16, frame, samples still to take (64 bits)
-constexpr int tile_slots(int out) { return out == 2 ? kTileSlotsMulti : kTileSlots; }
+constexpr int tile_slots(int out) { return out == 3 ? RT_TILE_SLOTS_MULTI_SMALL : out == 2 ? kTileSlotsMulti : kTileSlots; }
 constexpr int slot_bytes(int out) {     // per wave: stage (RGBX words, or 3 float sums per pixel) + header (+ next record)
-  return out == 0 ? 0 : out == 1 ? kTileSlots * (64 * 4 + kSlotHdr * 4) : kTileSlotsMulti * (3 * 64 * 4 + kSlotHdr * 4 + 72 * 2);
+  return out == 0 ? 0 : out == 1 ? kTileSlots * (64 * 4 + kSlotHdr * 4) : tile_slots(out) * (3 * 64 * 4 + kSlotHdr * 4 + 72 * 2);
 }
 // meta word of a SLOTS record: level (7 bits) | slot * 64 + pixel (9 bits) | object (12 bits, from bit 20)
 __device__ __forceinline__ uint32_t pack_meta_slot(int level, int slotpix, int object) {
@@ -1927,6 +1930,7 @@ __device__ __forceinline__ int meta_slotpix(uint32_t m) { return int((m >> 7) & 
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
 constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
+constexpr int ring_of(int out) { return out == 3 ? 1 : kRing; }   // (one entry costs the one-sample path 9 %; OUT = 3 buys a workgroup per CU with it)
 #ifndef RT_CLAIM
 #define RT_CLAIM 32    // slots per claim at most: one occupancy word's worth
 #endif
@@ -1950,7 +1954,7 @@ struct Queue {
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
 constexpr int wave_lds_bytes(bool refr, int out = 0) {
-  return queue_fields(refr, out) * (refr ? kBounceCapRefr : kBounceCap) * 4 + kRing * kVisTile * 2 + slot_bytes(out);
+  return queue_fields(refr, out) * (refr ? kBounceCapRefr : kBounceCap) * 4 + ring_of(out) * kVisTile * 2 + slot_bytes(out);
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -2014,11 +2018,14 @@ void queue_take_back(float* qf, const float* src, int at) {
 #endif
 
 // OUT: how finished pixels leave — 0: one by one (float / multi-sample / refraction paths), 1: whole tiles from
-// RGBX staging in per-wave tile slots, 2: the same with all samples of a pixel summed in the slot (MULTI)
+// RGBX staging in per-wave tile slots, 2: the same with all samples of a pixel summed in the slot (MULTI), 3: MULTI
+// with three slots and one ring entry per wave — 40.4 KB of LDS per workgroup besides the spheres, so that scenes of up
+// to 36 spheres keep FOUR workgroups per CU (OUT = 2: six slots, three workgroups, 133 VGPRs)
 template <int MODE, bool REFR, bool CUBES, bool GRID = false, int OUT = 0>
 __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
   // (the argument block is read through params_here(), phase by phase: never as a whole)
-  constexpr bool SLOTS = OUT != 0, MULTI = OUT == 2;
+  constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
+  constexpr int kRing = ring_of(OUT);
   static_assert(!GRID || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
   static_assert(!SLOTS || !REFR, "refractive scenes sum tree nodes into `accum`: no tile slots");
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
@@ -3367,18 +3374,20 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false
 }
 template <int OUT>
 RenderKernel pick_slot_kernel(int rng_mode, bool cubes, bool grid) {
-  if (grid && !cubes)
-    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true, OUT>
-                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true, OUT>;
+  if constexpr (OUT != 3)   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
+    if (grid && !cubes)
+      return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true, OUT>
+                                      : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true, OUT>;
   if (rng_mode == RT_RNG_KEYED)
     return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, false, OUT> : rt_stream_kernel<RT_RNG_KEYED, false, false, false, OUT>;
   return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, false, OUT> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, false, OUT>;
 }
 // out: 0 = finished pixels are stored one by one, 1 = tile by tile (the default for 8-bit frames), 2 = tile by
-// tile with all samples of a pixel in one launch
+// tile with all samples of a pixel in one launch, 3 = the same with fewer slots (small scenes: four workgroups per CU)
 RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false, int out = 0) {
   if (out == 1 && !refr) return pick_slot_kernel<1>(rng_mode, cubes, grid);
   if (out == 2 && !refr) return pick_slot_kernel<2>(rng_mode, cubes, grid);
+  if (out == 3 && !refr) return pick_slot_kernel<3>(rng_mode, cubes, false);
   if (grid && !refr && !cubes)
     return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true>
                                     : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true>;
@@ -3476,7 +3485,14 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   if (slots == 1 && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 1)) <
                         workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 0)))
     slots = 0;
-  const bool multi = slots == 2;
+  // all samples in one launch: the variant with three slots per wave where that buys a fourth workgroup per CU (scenes of
+  // up to 36 spheres: config 2 at 2 / 4 samples 513 -> 545 / 531 -> 568 Grays/s; on larger scenes, where three workgroups
+  // fit either way, it measured 9 % slower)
+  const bool listed = ctx->grid_dim > 0 || ctx->list_dim > 0;
+  if (slots == 2 && !listed && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3)) >
+                                   workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 2)))
+    slots = 3;
+  const bool multi = slots >= 2;
   const size_t vis_need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch) *
                           size_t(multi ? samples : 1);   // whole 8x8 tiles, odd pitch; MULTI: a record per sample
   if (stream_kernel && !ws) {  // primary-hit indices handed from the visibility pass to the stream kernel
@@ -3744,10 +3760,10 @@ int rt_create(int device_id, rt_ctx** out) {
   for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
     if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, true), big)) != hipSuccess)
       return bail(e, "hipFuncSetAttribute");
-  for (int out = 1; out <= 2; ++out) {
+  for (int out = 1; out <= 3; ++out) {
     const size_t bigs = stream_lds(RT_MAX_SPHERES, false, out);
     for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-      for (int v = 0; v < 3; ++v)   // plain, cubes, grid
+      for (int v = 0; v < (out == 3 ? 2 : 3); ++v)   // plain, cubes, grid
         if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2, out), bigs)) != hipSuccess)
           return bail(e, "hipFuncSetAttribute");
   }

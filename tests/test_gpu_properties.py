@@ -7,7 +7,7 @@ import pytest
 
 import raytracer_amd
 from raytracer_amd import _lib, tiling
-from raytracer_amd.scenes import RtCamera, default_scene, generate_scene, orbit_camera
+from raytracer_amd.scenes import Cube, RtCamera, Vector3, default_scene, generate_scene, orbit_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -444,6 +444,13 @@ def test_samples_in_one_launch_change_no_byte(renderer):
     cases = [(generate_scene(8, 1, keep_default=True), 960, 540, 5, (2, 4)), (generate_scene(64, 2), 640, 360, 8, (3,)),
              (default_scene(), 333, 187, 5, (2, 7)), (generate_scene(300, 7), 320, 180, 5, (2,)),
              (cube_scene(), 320, 179, 5, (2,)), (default_scene(), 64, 48, 3, (64, 65)), (default_scene(), 5, 3, 5, (2,))]
+    # (up to 36 spheres — a cube counts as two — the stream kernel runs its three-slot variant at four workgroups per
+    # CU, above that the six-slot one at three: 30 spheres and 5 cubes take the latter's cube variant)
+    many = generate_scene(30, 5)
+    box_m = cube_scene()["spheres"][-1].material
+    many["spheres"] = list(many["spheres"]) + [Cube(Vector3(-3.0 + 1.5 * i, -1.0, -7.0 - i), Vector3(-2.4 + 1.5 * i, -0.3, -6.2 - i), box_m)
+                                               for i in range(5)]
+    cases.append((many, 322, 181, 4, (2, 3)))
     try:
         for scene, w, h, D, spps in cases:
             for spp in spps:
