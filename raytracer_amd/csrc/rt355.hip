@@ -2021,12 +2021,16 @@ void queue_take_back(float* qf, const float* src, int at) {
 // RGBX staging in per-wave tile slots, 2: the same with all samples of a pixel summed in the slot (MULTI), 3: MULTI
 // with three slots and one ring entry per wave — 40.4 KB of LDS per workgroup besides the spheres, so that scenes of up
 // to 36 spheres keep FOUR workgroups per CU (OUT = 2: six slots, three workgroups, 133 VGPRs)
-template <int MODE, bool REFR, bool CUBES, bool GRID = false, int OUT = 0>
-__global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+// GRID: 0 = few spheres (bit tables), 1 = many spheres (grid or lists for reflection rays, lists for shadow rays), 2 = the
+// same compiled for three waves per SIMD, i.e. up to 168 VGPRs — from 513 spheres on, the sphere list leaves LDS for three
+// workgroups per CU anyway, and at 128 VGPRs the variant spills (config 4: 271 -> 280 Grays/s; at 400 spheres, where four
+// workgroups fit, three measured 12 % slower)
+template <int MODE, bool REFR, bool CUBES, int GRID = 0, int OUT = 0>
+__global__ __launch_bounds__(kBlock, (OUT == 2 || GRID == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
   constexpr int kRing = ring_of(OUT);
-  static_assert(!GRID || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
+  static_assert(GRID == 0 || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
   static_assert(!SLOTS || !REFR, "refractive scenes sum tree nodes into `accum`: no tile slots");
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
   constexpr int kWaveLdsBytes = wave_lds_bytes(REFR, OUT);
@@ -2561,7 +2565,7 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
           const RenderParams& p = params_here();                     // the lights and tables of lighting(): dead after it
           LateFromRecord late{p, late_state, q, e, meta, base, lane_here()};
           const uint32_t level_key = mix(pixel_key, uint32_t(meta_level(meta) + 1));
-          cont = shade_hit<MODE, CUBES, GRID>(p, sg, meta_object(meta), px, py, pz, dx, dy, dz, level_key,
+          cont = shade_hit<MODE, CUBES, (GRID != 0)>(p, sg, meta_object(meta), px, py, pz, dx, dy, dz, level_key,
                                         tr, tg, tb, ar, ag, ab, ox, oy, oz, late);
         }
         const RenderParams& p = params_here();
@@ -2572,7 +2576,7 @@ __global__ __launch_bounds__(kBlock, OUT == 2 ? 3 : RT_WAVES_PER_SIMD) void rt_s
           float t;
           int idx2, face;
           ++n_trace;
-          if constexpr (GRID) {
+          if constexpr (GRID != 0) {
             if (p.list_dim > 0) nearest_list(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2);
             else nearest_grid(p, sg, ox, oy, oz, dx, dy, dz, t, idx2);
             face = 0;
@@ -3086,8 +3090,8 @@ size_t stream_lds(int n_spheres, bool refr = false, int out = 0) {
   return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * (kBlock / 64);
 }
 // resident workgroups of the stream kernel per CU: one per wave slot of a SIMD, or as many as 160 KB of LDS hold
-unsigned workgroups_per_cu(size_t lds) {
-  return unsigned(std::max<size_t>(1, std::min<size_t>(RT_WAVES_PER_SIMD, size_t(160 * 1024) / lds)));
+unsigned workgroups_per_cu(size_t lds, unsigned waves_per_simd = RT_WAVES_PER_SIMD) {
+  return unsigned(std::max<size_t>(1, std::min<size_t>(waves_per_simd, size_t(160 * 1024) / lds)));
 }
 size_t pixel_lds(int n_spheres) { return geom_lds(n_spheres) + size_t(kTileW) * kTileH * 4 + 16; }
 
@@ -3373,24 +3377,32 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false
   return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false>;
 }
 template <int OUT>
-RenderKernel pick_slot_kernel(int rng_mode, bool cubes, bool grid) {
-  if constexpr (OUT != 3)   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
+RenderKernel pick_slot_kernel(int rng_mode, bool cubes, int grid) {
+  if constexpr (OUT != 3) {   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
+    if constexpr (OUT == 1)   // (OUT = 2 is compiled for three waves per SIMD as it is)
+      if (grid == 2 && !cubes)
+        return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 2, OUT>
+                                        : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 2, OUT>;
     if (grid && !cubes)
-      return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true, OUT>
-                                      : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true, OUT>;
+      return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 1, OUT>
+                                      : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 1, OUT>;
+  }
   if (rng_mode == RT_RNG_KEYED)
-    return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, false, OUT> : rt_stream_kernel<RT_RNG_KEYED, false, false, false, OUT>;
-  return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, false, OUT> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, false, OUT>;
+    return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, 0, OUT> : rt_stream_kernel<RT_RNG_KEYED, false, false, 0, OUT>;
+  return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, 0, OUT> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 0, OUT>;
 }
 // out: 0 = finished pixels are stored one by one, 1 = tile by tile (the default for 8-bit frames), 2 = tile by
 // tile with all samples of a pixel in one launch, 3 = the same with fewer slots (small scenes: four workgroups per CU)
-RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, bool grid = false, int out = 0) {
+RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, int grid = 0, int out = 0) {
   if (out == 1 && !refr) return pick_slot_kernel<1>(rng_mode, cubes, grid);
   if (out == 2 && !refr) return pick_slot_kernel<2>(rng_mode, cubes, grid);
-  if (out == 3 && !refr) return pick_slot_kernel<3>(rng_mode, cubes, false);
+  if (out == 3 && !refr) return pick_slot_kernel<3>(rng_mode, cubes, 0);
+  if (grid == 2 && !refr && !cubes)
+    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 2>
+                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 2>;
   if (grid && !refr && !cubes)
-    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, true>
-                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, true>;
+    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 1>
+                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 1>;
   if (rng_mode == RT_RNG_KEYED) {
     if (refr) return cubes ? rt_stream_kernel<RT_RNG_KEYED, true, true> : rt_stream_kernel<RT_RNG_KEYED, true, false>;
     return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true> : rt_stream_kernel<RT_RNG_KEYED, false, false>;
@@ -3651,7 +3663,9 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         // (and never more than the LDS lets stay resident)
-        const unsigned per_cu = workgroups_per_cu(lds);
+        // (many-sphere scenes: the variant compiled for three waves per SIMD where the LDS holds no more anyway)
+        const int listed = (p.grid_dim > 0 || p.list_dim > 0) ? (workgroups_per_cu(lds) <= 3u ? 2 : 1) : 0;
+        const unsigned per_cu = workgroups_per_cu(lds, (slots == 2 || listed == 2) ? 3u : unsigned(RT_WAVES_PER_SIMD));
         const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
@@ -3660,7 +3674,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi), vgrid, dim3(kBlock), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples)
-          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, p.grid_dim > 0 || p.list_dim > 0, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
+          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, listed, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
         if (refr && s + 1 == samples) {   // (never MULTI)
           if (p.defer_sparse)
             hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf)),
@@ -3758,13 +3772,15 @@ int rt_create(int device_id, rt_ctx** out) {
         if ((e = allow_big_lds(pick_stream_kernel(mode, r != 0, c != 0), r ? bigr : big)) != hipSuccess)
           return bail(e, "hipFuncSetAttribute");
   for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-    if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, true), big)) != hipSuccess)
-      return bail(e, "hipFuncSetAttribute");
+    for (int g = 1; g <= 2; ++g)
+      if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), big)) != hipSuccess ||
+          (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute");
   for (int out = 1; out <= 3; ++out) {
     const size_t bigs = stream_lds(RT_MAX_SPHERES, false, out);
     for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
       for (int v = 0; v < (out == 3 ? 2 : 3); ++v)   // plain, cubes, grid
-        if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2, out), bigs)) != hipSuccess)
+        if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2 ? 1 : 0, out), bigs)) != hipSuccess)
           return bail(e, "hipFuncSetAttribute");
   }
   if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
