@@ -788,10 +788,16 @@ __device__ __forceinline__ bool box_in_double_cone(const float4 lo, const float4
   const RayCone back{-cone.ax, -cone.ay, -cone.az, cone.sin_t, cone.cos2_t};
   return sphere_in_cone(s, cone, ox, oy, oz) || sphere_in_cone(s, back, ox, oy, oz);
 }
-// (`first` = the ballot of sphere_in_cone over spheres 0..63, which the caller has taken already)
+// (`first` = the ballot of sphere_in_cone over spheres 0..63, which the caller has taken already; `kept`: the caller has
+// all the ballots — lane c of keep_lo / keep_hi holds that of spheres 64 c .. 64 c + 63)
+__device__ __forceinline__ unsigned long long mask_of_chunk(uint32_t keep_lo, uint32_t keep_hi, int c) {
+  return (unsigned long long)uint32_t(__builtin_amdgcn_readlane(int(keep_lo), c)) |
+         ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(int(keep_hi), c)) << 32);
+}
 template <int NP>
 __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg, const CamGroup* __restrict__ camtab,
                                                    int n, int lane, const RayCone& cone, unsigned long long first,
+                                                   bool kept, uint32_t keep_lo, uint32_t keep_hi,
                                                    float ox, float oy, float oz, const float (&dx)[NP],
                                                    const float (&dy)[NP], const float (&dz)[NP], float (&best_t)[NP],
                                                    int (&best_i)[NP]) {
@@ -806,7 +812,9 @@ __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg
   cgeom_t geom = as_const(gg);
   for (int base = 0; base < n; base += 64) {
     unsigned long long m = first;
-    if (base != 0) {
+    if (kept) {
+      m = mask_of_chunk(keep_lo, keep_hi, base >> 6);
+    } else if (base != 0) {
       const int i = base + lane;
       m = __ballot(i < n && sphere_in_cone(gg[i < n ? i : n - 1], cone, ox, oy, oz));
     }
@@ -1548,9 +1556,10 @@ __device__ __forceinline__ RayCone bundle_cone(const RenderParams& p, const rt_c
 }
 
 // One block of the visibility pass: kVisTiles 8x8 tiles side by side, rows row0 .. row0 + 7 of the window, one wave.
-template <int MODE, bool CUBES, bool MULTI>
+template <int MODE, bool CUBES, bool MULTI, bool MANY = false>
 __device__ __forceinline__ void visibility_block(const RenderParams& p, const int frame, const int row0, const int col0,
-                                                 const int lane) {
+                                                 const int lane, const uint32_t region_lo = 0u, const uint32_t region_hi = 0u) {
+  constexpr bool region_kept = MANY;      // (scenes of more than 64 spheres without cubes)
   // lane (lx, ly) traces pixel (lx, ly) of each tile
   constexpr int NT = kVisTiles;
   const int lx = lane & 7, ly = lane >> 3;
@@ -1582,7 +1591,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
   // are requested now, so the load is covered by the cone's arithmetic.
   const bool cull = RT_VIS_SKIP ? p.n_spheres > 0 : p.n_spheres > kVisCullFrom;
   float4 first_sphere = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (cull) first_sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
+  if (cull && !region_kept) first_sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
   if (live[0] || cull) {                                  // (a later tile's pixel is live only if the first one's is;
     const FrameRec fr = as_const(p.frames)[frame];        //  with the cull all lanes take part in its ballots)
     const rt_camera& cam = fr.cam;
@@ -1590,11 +1599,30 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
     const CamGroup* table = p.camtab + size_t(frame) * cam_groups_stride(p.n_spheres);
     RayCone cone{0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned long long first = 0ull;                      // spheres 0..63 that reach into the block's cone
+    // Many spheres (region_kept): the region has culled ALL spheres against its own cone (lane c of region_lo / _hi: the
+    // ballot of spheres 64 c ..); the block looks only at chunks that kept something, tests only the kept spheres against
+    // its narrower cone, and keeps its ballots the same way — so it knows whether ANY sphere reaches it before it
+    // builds a ray, as blocks of small scenes do.
+    uint32_t keep_lo = 0u, keep_hi = 0u;
+    unsigned long long reached = 0ull;
     if (cull) {
       const int ya = tile_rows_uniform(p) ? tile_row_base(p, row0) : row_of(p, row0);
       const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
       cone = bundle_cone(p, cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
-      first = __ballot(lane < p.n_spheres && sphere_in_cone(first_sphere, cone, cam.origin[0], cam.origin[1], cam.origin[2]));
+      if (region_kept) {
+        for (int c = 0; c * 64 < p.n_spheres; ++c) {
+          const unsigned long long rm = mask_of_chunk(region_lo, region_hi, c);
+          if (rm == 0ull) continue;
+          bool in = false;
+          if ((rm >> lane) & 1ull) in = sphere_in_cone(p.geom[c * 64 + lane], cone, cam.origin[0], cam.origin[1], cam.origin[2]);
+          const unsigned long long m = __ballot(in);
+          if (lane == c) { keep_lo = uint32_t(m); keep_hi = uint32_t(m >> 32); }
+          reached |= m;
+        }
+      } else {
+        first = __ballot(lane < p.n_spheres && sphere_in_cone(first_sphere, cone, cam.origin[0], cam.origin[1], cam.origin[2]));
+        reached = first;
+      }
     }
     // a block that no sphere reaches builds no rays: all its pixels miss (with more than 64 spheres the later
     // chunks are not looked at here, and with cubes every ray is needed for them)
@@ -1610,7 +1638,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
                                                                      cam.origin[1], cam.origin[2])) != 0ull;
       }
     }
-    const bool need_rays = !RT_VIS_SKIP || cube_reach || first != 0ull || p.n_spheres > 64;
+    const bool need_rays = !RT_VIS_SKIP || cube_reach || reached != 0ull || (p.n_spheres > 64 && !region_kept);
 #endif
     // (nothing to write at all: a sample before the last of the MULTI path leaves only records and `present` bits
     // of tiles it hit; on the deferred-output path — refractive scenes — every pixel comes from rt_resolve_kernel)
@@ -1639,8 +1667,8 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
                         dz[q]);
     }
     if (p.n_spheres > kVisCullFrom)
-      primary_hit_culled<NT>(p.geom, table, p.n_spheres, lane, cone, first, cam.origin[0], cam.origin[1],
-                             cam.origin[2], dx, dy, dz, t, idx);
+      primary_hit_culled<NT>(p.geom, table, p.n_spheres, lane, cone, first, region_kept, keep_lo, keep_hi, cam.origin[0],
+                             cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     else   // few spheres: every group is scanned (pipelined scalar loads: cheaper here than group-by-group fetches)
       primary_hit_n<NT>(p.geom, table, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
@@ -1776,13 +1804,17 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
 #define RT_VIS_ROWS 4
 #endif
 constexpr int kVisRows = RT_VIS_ROWS;
-template <int MODE, bool CUBES, bool MULTI = false>
+template <int MODE, bool CUBES, bool MULTI = false, bool MANY = false>
 __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
+  static_assert(!MANY || !CUBES, "the many-sphere form of the pass exists for scenes without cubes");
   constexpr int NT = kVisTiles;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
   const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * kVisRows);   // window coordinates
   if (p.nx - col0 <= 0) return;                           // wave-uniform: beyond the right edge
+  constexpr bool region_kept = MANY;
+  bool region_any = false;
+  uint32_t region_lo = 0u, region_hi = 0u;      // many spheres: lane c holds the ballot of spheres 64 c .. against the region's cone
   if constexpr (RT_VIS_SKIP && kVisRows > 1) {
     const long long frame_px = (long long)frame * p.frame_stride_px;
     const bool whole = rowR + 8 * kVisRows <= p.n_rows && p.nx - col0 >= 8 * NT;
@@ -1791,9 +1823,29 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     const bool black_owed = (MULTI ? p.sample_index + 1 == p.n_samples : p.n_samples == 1) && !p.out_f32 && !p.out_hit &&
                             (!p.defer_output || p.defer_sparse) && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
                             (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
-    if ((nothing_owed || black_owed) && p.n_spheres <= 64 && (!CUBES || (p.n_spheres > 0 && p.n_cubes <= 64))) {
-      bool any = false;
-      if (p.n_spheres > 0) {
+    if constexpr (MANY) {
+      {                         // many spheres: every chunk of 64 against the region's cone, the ballots kept for the blocks
+        const FrameRec fr = as_const(p.frames)[frame];
+        const int last = min(rowR + 8 * kVisRows, p.n_rows) - 1;
+        const int ya = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + rowR : row_of(p, rowR);
+        const int yb = (p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + last : row_of(p, last)) + 1;
+        const RayCone cone = bundle_cone(p, fr.cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
+        unsigned long long reached = 0ull;
+        float4 sphere = p.geom[lane];
+        for (int c = 0; c * 64 < p.n_spheres; ++c) {
+          const int i = c * 64 + lane, nxt = min(i + 64, p.n_spheres - 1);
+          const float4 ahead = p.geom[nxt];                 // (the next chunk's spheres are on their way during this one's test)
+          const unsigned long long m = __ballot(i < p.n_spheres && sphere_in_cone(sphere, cone, fr.cam.origin[0], fr.cam.origin[1], fr.cam.origin[2]));
+          if (lane == c) { region_lo = uint32_t(m); region_hi = uint32_t(m >> 32); }
+          reached |= m;
+          sphere = ahead;
+        }
+        region_any = reached != 0ull;
+      }
+    }
+    if ((nothing_owed || black_owed) && (p.n_spheres <= 64 || region_kept) && (!CUBES || (p.n_spheres > 0 && p.n_cubes <= 64))) {
+      bool any = region_any;
+      if (p.n_spheres > 0 && !region_kept) {
         const float4 sphere = p.geom[lane < p.n_spheres ? lane : p.n_spheres - 1];
         const FrameRec fr = as_const(p.frames)[frame];
         const int last = min(rowR + 8 * kVisRows, p.n_rows) - 1;
@@ -1841,7 +1893,7 @@ __global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(con
     // and everything derived from them would not fit the scalar registers)
     int lane_b = int(threadIdx.x) & 63;
     asm volatile("" : "+v"(lane_b));
-    visibility_block<MODE, CUBES, MULTI>(params_here(), frame, row0, col0, lane_b);
+    visibility_block<MODE, CUBES, MULTI, MANY>(params_here(), frame, row0, col0, lane_b, region_lo, region_hi);
   }
 }
 
@@ -3368,7 +3420,11 @@ void build_occluder_table(const float* geom4, int n, const DevLights& L, std::ve
 
 // kernel variants: RNG mode x refraction in the scene x cubes in the scene
 using RenderKernel = void (*)(const RenderParams);
-RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false) {
+RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false, bool many = false) {
+  if (many && !cubes && RT_VIS_SKIP && kVisRows > 1) {      // more than 64 spheres: the region culls them all, chunk by chunk
+    if (multi) return rng_mode == RT_RNG_KEYED ? rt_visibility_kernel<RT_RNG_KEYED, false, true, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false, true, true>;
+    return rng_mode == RT_RNG_KEYED ? rt_visibility_kernel<RT_RNG_KEYED, false, false, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false, false, true>;
+  }
   if (multi) {
     if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true, true> : rt_visibility_kernel<RT_RNG_KEYED, false, true>;
     return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false, true>;
@@ -3671,7 +3727,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
         // keeps the last call's contents)
         if (!multi || s == 0) RT_HIP(ctx, hipMemsetAsync(d_chunk, 0, chunk_need, ctx->stream));
-        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi), vgrid, dim3(kBlock), vlds, ctx->stream, p);
+        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi, ctx->n_spheres > 64), vgrid, dim3(kBlock), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples)
           hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, listed, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
