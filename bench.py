@@ -62,6 +62,8 @@ WORKLOADS = {
     "c4": (7680, 4320, 1024, 3, False, 5, "config 4: 7680x4320, 1024 spheres, depth 5 (use --frames 16)"),
     "c5": (1920, 1080, 8, 1, True, 5, "config 5: 1080p camera-orbit animation over config 2's scene (use --frames 256)"),
     "s400": (1920, 1080, 400, 4, False, 5, "diagnostic: 1920x1080, 400 spheres, depth 5 (the list kernels below 513 spheres)"),
+    "s700": (1920, 1080, 700, 5, False, 5, "diagnostic: 1920x1080, 700 spheres, depth 5 (the list kernels' eight-wave workgroups)"),
+    "s2000": (1920, 1080, 2000, 6, False, 5, "diagnostic: 1920x1080, 2000 spheres, depth 5"),
     # SURVEY.md 8(f) rows measured beside the headline (not bench lines of BASELINE.json)
     "refr": (1920, 1080, 5, 0, True, 5, "8f rank 2: refractive_scene() (default scene + glass) 1920x1080 depth 5"),
     "cubes": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene() (default scene + 3 opaque cubes) 1920x1080 depth 5"),

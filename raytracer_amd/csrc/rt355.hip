@@ -2074,11 +2074,12 @@ void queue_take_back(float* qf, const float* src, int at) {
 // with three slots and one ring entry per wave — 40.4 KB of LDS per workgroup besides the spheres, so that scenes of up
 // to 36 spheres keep FOUR workgroups per CU (OUT = 2: six slots, three workgroups, 133 VGPRs)
 // GRID: 0 = few spheres (bit tables), 1 = many spheres (grid or lists for reflection rays, lists for shadow rays), 2 = the
-// same compiled for three waves per SIMD, i.e. up to 168 VGPRs — from 513 spheres on, the sphere list leaves LDS for three
-// workgroups per CU anyway, and at 128 VGPRs the variant spills (config 4: 271 -> 280 Grays/s; at 400 spheres, where four
-// workgroups fit, three measured 12 % slower)
+// same as workgroups of EIGHT waves around one copy of the sphere list: from 513 spheres on a copy per four waves leaves
+// LDS for three workgroups per CU, one per eight waves for two of twice the size (config 4: 308 -> 334 Grays/s).
+// (Before that, 2 was the four-wave form compiled for three waves per SIMD — 156 VGPRs, nothing spilled: 271 -> 281.)
 template <int MODE, bool REFR, bool CUBES, int GRID = 0, int OUT = 0>
-__global__ __launch_bounds__(kBlock, (OUT == 2 || GRID == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+__global__ __launch_bounds__((GRID == 2 ? 512 : kBlock), (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+  constexpr int kThreads = GRID == 2 ? 512 : kBlock;
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
   constexpr int kRing = ring_of(OUT);
@@ -2102,9 +2103,9 @@ __global__ __launch_bounds__(kBlock, (OUT == 2 || GRID == 2) ? 3 : RT_WAVES_PER_
     const RenderParams& p = params_here();
     const int geom_bytes = (p.n_spheres + 2 * p.n_cubes) * 16;
     mine = smem + geom_bytes + wave * kWaveLdsBytes;
-    for (int i = tid; i < p.n_spheres; i += kBlock) sg[i] = p.geom[i];
+    for (int i = tid; i < p.n_spheres; i += kThreads) sg[i] = p.geom[i];
     if constexpr (CUBES)
-      for (int i = tid; i < 2 * p.n_cubes; i += kBlock) sg[p.n_spheres + i] = p.cubes[i];
+      for (int i = tid; i < 2 * p.n_cubes; i += kThreads) sg[p.n_spheres + i] = p.cubes[i];
     const int tiles_per_frame = p.tile_pitch * p.tiles8_y;   // tile ids, padding ids (no record, no occupancy bit) included
     total_tiles = tiles_per_frame * p.n_frames;
   }
@@ -2122,8 +2123,8 @@ __global__ __launch_bounds__(kBlock, (OUT == 2 || GRID == 2) ? 3 : RT_WAVES_PER_
   constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : SLOTS ? 12 : 13, kFKey = REFR ? 11 : SLOTS ? 13 : 14;   // field numbers
   __syncthreads();   // the only workgroup-wide synchronisation
 
-  const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kBlock / 64) + wave);
-  const int n_waves = int(gridDim.x) * (kBlock / 64);
+  const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kThreads / 64) + wave);
+  const int n_waves = int(gridDim.x) * (kThreads / 64);
   uint32_t n_trace = 0, n_shade = 0;
   [[maybe_unused]] unsigned long long st_fetch = 0, st_pop = 0, st_light = 0, st_near = 0;     // (read in RT_STAMPS builds only)
   [[maybe_unused]] const unsigned long long st_begin = RT_NOW();
@@ -3138,8 +3139,8 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres, bool refr = false, int out = 0) {
-  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * (kBlock / 64);
+size_t stream_lds(int n_spheres, bool refr = false, int out = 0, int waves = kBlock / 64) {
+  return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * size_t(waves);
 }
 // resident workgroups of the stream kernel per CU: one per wave slot of a SIMD, or as many as 160 KB of LDS hold
 unsigned workgroups_per_cu(size_t lds, unsigned waves_per_simd = RT_WAVES_PER_SIMD) {
@@ -3557,6 +3558,17 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // up to 36 spheres: config 2 at 2 / 4 samples 513 -> 545 / 531 -> 568 Grays/s; on larger scenes, where three workgroups
   // fit either way, it measured 9 % slower)
   const bool listed = ctx->grid_dim > 0 || ctx->list_dim > 0;
+  // Many spheres (the list / grid kernels): every workgroup holds a copy of the sphere list, 16 KB at 1024 spheres, so only
+  // three workgroups of four waves fit a CU.  Workgroups of EIGHT waves share one copy: two of them (80 KB each at 1024
+  // spheres) are 16 waves per CU.  Taken where that is more waves than the four-wave form holds, if need be without
+  // tile slots (config 4: 308 -> 334 Grays/s).
+  bool eight_waves = false;
+  if (stream_kernel && !refr && !cubes && listed && slots < 2) {
+    const unsigned waves4 = 4u * workgroups_per_cu(stream_lds(ctx->n_spheres, false, slots));
+    for (int sl : {slots, 0}) {
+      if (8u * workgroups_per_cu(stream_lds(ctx->n_spheres, false, sl, 8), 2u) > waves4) { eight_waves = true; slots = sl; break; }
+    }
+  }
   if (slots == 2 && !listed && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3)) >
                                    workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 2)))
     slots = 3;
@@ -3680,7 +3692,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   }
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
-    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots) : pixel_lds(ctx->n_spheres);
+    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots, eight_waves ? 8 : 4) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
@@ -3719,10 +3731,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         // (and never more than the LDS lets stay resident)
-        // (many-sphere scenes: the variant compiled for three waves per SIMD where the LDS holds no more anyway)
-        const int listed = (p.grid_dim > 0 || p.list_dim > 0) ? (workgroups_per_cu(lds) <= 3u ? 2 : 1) : 0;
-        const unsigned per_cu = workgroups_per_cu(lds, (slots == 2 || listed == 2) ? 3u : unsigned(RT_WAVES_PER_SIMD));
-        const dim3 sgrid(std::min((grid.x + 3u) / 4u, unsigned(ctx->n_cus) * per_cu), 1, 1);
+        // (many-sphere scenes: 1 = the list / grid kernel, 2 = its form with eight waves per workgroup)
+        const int list_kernel = (p.grid_dim > 0 || p.list_dim > 0) ? (eight_waves ? 2 : 1) : 0;
+        const unsigned per_cu = eight_waves ? workgroups_per_cu(lds, 2u) : workgroups_per_cu(lds, slots == 2 ? 3u : unsigned(RT_WAVES_PER_SIMD));
+        const unsigned threads = eight_waves ? 512u : unsigned(kBlock);
+        const dim3 sgrid(std::min((grid.x + threads / 64 - 1) / (threads / 64), unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
         // keeps the last call's contents)
@@ -3730,7 +3743,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi, ctx->n_spheres > 64), vgrid, dim3(kBlock), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples)
-          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, listed, slots), sgrid, dim3(kBlock), lds, ctx->stream, p);
+          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, list_kernel, slots), sgrid, dim3(threads), lds, ctx->stream, p);
         if (refr && s + 1 == samples) {   // (never MULTI)
           if (p.defer_sparse)
             hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf)),
@@ -3829,8 +3842,8 @@ int rt_create(int device_id, rt_ctx** out) {
           return bail(e, "hipFuncSetAttribute");
   for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
     for (int g = 1; g <= 2; ++g)
-      if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), big)) != hipSuccess ||
-          (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
+      if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), g == 2 ? size_t(160 * 1024) : big)) != hipSuccess ||
+          (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), g == 2 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
   for (int out = 1; out <= 3; ++out) {
     const size_t bigs = stream_lds(RT_MAX_SPHERES, false, out);
