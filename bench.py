@@ -50,7 +50,7 @@ PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 
 PMC = {
     "c2": dict(profile="profiles/r2x_c2_rt_{stream,visibility}_kernel.txt", flops=3.956e+11, valu=8.537e+09, salu=3.348e+09, hbm_bytes=1.187e+10, rays=7.863e+09),
     "t64": dict(profile="profiles/r2x_t64_rt_{stream,visibility}_kernel.txt", flops=3.483e+11, valu=7.665e+09, salu=3.009e+09, hbm_bytes=1.269e+10, rays=6.428e+09),
-    "c4": dict(profile="profiles/r2z_c4_rt_{stream,visibility}_kernel.txt", flops=3.449e+11, valu=6.654e+09, salu=1.892e+09, hbm_bytes=9.134e+09, rays=3.36e+09),
+    "c4": dict(profile="profiles/r2z_c4_rt_{stream,visibility}_kernel.txt", flops=3.45e+11, valu=6.658e+09, salu=1.893e+09, hbm_bytes=1.08e+10, rays=3.36e+09),
 }
 
 WORKLOADS = {
