@@ -2077,9 +2077,10 @@ void queue_take_back(float* qf, const float* src, int at) {
 // same as workgroups of EIGHT waves around one copy of the sphere list: from 513 spheres on a copy per four waves leaves
 // LDS for three workgroups per CU, one per eight waves for two of twice the size (config 4: 308 -> 334 Grays/s).
 // (Before that, 2 was the four-wave form compiled for three waves per SIMD — 156 VGPRs, nothing spilled: 271 -> 281.)
+// 3 = SIXTEEN waves around one copy (from ~1100 spheres on, where two eight-wave workgroups no longer fit a CU).
 template <int MODE, bool REFR, bool CUBES, int GRID = 0, int OUT = 0>
-__global__ __launch_bounds__((GRID == 2 ? 512 : kBlock), (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
-  constexpr int kThreads = GRID == 2 ? 512 : kBlock;
+__global__ __launch_bounds__((GRID == 3 ? 1024 : GRID == 2 ? 512 : kBlock), (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+  constexpr int kThreads = GRID == 3 ? 1024 : GRID == 2 ? 512 : kBlock;
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
   constexpr int kRing = ring_of(OUT);
@@ -3436,10 +3437,14 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false
 template <int OUT>
 RenderKernel pick_slot_kernel(int rng_mode, bool cubes, int grid) {
   if constexpr (OUT != 3) {   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
-    if constexpr (OUT == 1)   // (OUT = 2 is compiled for three waves per SIMD as it is)
+    if constexpr (OUT == 1) {   // (OUT = 2 is compiled for three waves per SIMD as it is)
+      if (grid == 3 && !cubes)
+        return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 3, OUT>
+                                        : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 3, OUT>;
       if (grid == 2 && !cubes)
         return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 2, OUT>
                                         : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 2, OUT>;
+    }
     if (grid && !cubes)
       return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 1, OUT>
                                       : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 1, OUT>;
@@ -3454,6 +3459,9 @@ RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, int grid = 
   if (out == 1 && !refr) return pick_slot_kernel<1>(rng_mode, cubes, grid);
   if (out == 2 && !refr) return pick_slot_kernel<2>(rng_mode, cubes, grid);
   if (out == 3 && !refr) return pick_slot_kernel<3>(rng_mode, cubes, 0);
+  if (grid == 3 && !refr && !cubes)
+    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 3>
+                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 3>;
   if (grid == 2 && !refr && !cubes)
     return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 2>
                                     : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 2>;
@@ -3562,12 +3570,16 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // three workgroups of four waves fit a CU.  Workgroups of EIGHT waves share one copy: two of them (80 KB each at 1024
   // spheres) are 16 waves per CU.  Taken where that is more waves than the four-wave form holds, if need be without
   // tile slots (config 4: 308 -> 334 Grays/s).
-  bool eight_waves = false;
+  // (and from ~1100 spheres on ONE workgroup of sixteen waves: 2000 spheres 125 -> see DESIGN)
+  int wg_waves = 4;
   if (stream_kernel && !refr && !cubes && listed && slots < 2) {
-    const unsigned waves4 = 4u * workgroups_per_cu(stream_lds(ctx->n_spheres, false, slots));
-    for (int sl : {slots, 0}) {
-      if (8u * workgroups_per_cu(stream_lds(ctx->n_spheres, false, sl, 8), 2u) > waves4) { eight_waves = true; slots = sl; break; }
-    }
+    unsigned best = 4u * workgroups_per_cu(stream_lds(ctx->n_spheres, false, slots));
+    const int slots4 = slots;
+    for (int wv : {8, 16})
+      for (int sl : {slots4, 0}) {
+        const unsigned waves = unsigned(wv) * workgroups_per_cu(stream_lds(ctx->n_spheres, false, sl, wv), unsigned(16 / wv));
+        if (stream_lds(ctx->n_spheres, false, sl, wv) <= size_t(160 * 1024) && waves > best) { best = waves; wg_waves = wv; slots = sl; }
+      }
   }
   if (slots == 2 && !listed && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3)) >
                                    workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 2)))
@@ -3692,7 +3704,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   }
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
-    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots, eight_waves ? 8 : 4) : pixel_lds(ctx->n_spheres);
+    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots, wg_waves) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
@@ -3731,10 +3743,10 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         // (and never more than the LDS lets stay resident)
-        // (many-sphere scenes: 1 = the list / grid kernel, 2 = its form with eight waves per workgroup)
-        const int list_kernel = (p.grid_dim > 0 || p.list_dim > 0) ? (eight_waves ? 2 : 1) : 0;
-        const unsigned per_cu = eight_waves ? workgroups_per_cu(lds, 2u) : workgroups_per_cu(lds, slots == 2 ? 3u : unsigned(RT_WAVES_PER_SIMD));
-        const unsigned threads = eight_waves ? 512u : unsigned(kBlock);
+        // (many-sphere scenes: 1 = the list / grid kernel, 2 / 3 = its forms with eight / sixteen waves per workgroup)
+        const int list_kernel = (p.grid_dim > 0 || p.list_dim > 0) ? (wg_waves == 16 ? 3 : wg_waves == 8 ? 2 : 1) : 0;
+        const unsigned per_cu = wg_waves > 4 ? workgroups_per_cu(lds, unsigned(16 / wg_waves)) : workgroups_per_cu(lds, slots == 2 ? 3u : unsigned(RT_WAVES_PER_SIMD));
+        const unsigned threads = unsigned(wg_waves) * 64u;
         const dim3 sgrid(std::min((grid.x + threads / 64 - 1) / (threads / 64), unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
@@ -3841,9 +3853,9 @@ int rt_create(int device_id, rt_ctx** out) {
         if ((e = allow_big_lds(pick_stream_kernel(mode, r != 0, c != 0), r ? bigr : big)) != hipSuccess)
           return bail(e, "hipFuncSetAttribute");
   for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-    for (int g = 1; g <= 2; ++g)
-      if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), g == 2 ? size_t(160 * 1024) : big)) != hipSuccess ||
-          (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), g == 2 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
+    for (int g = 1; g <= 3; ++g)
+      if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), g >= 2 ? size_t(160 * 1024) : big)) != hipSuccess ||
+          (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), g >= 2 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
   for (int out = 1; out <= 3; ++out) {
     const size_t bigs = stream_lds(RT_MAX_SPHERES, false, out);
