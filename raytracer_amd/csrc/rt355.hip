@@ -1969,7 +1969,7 @@ static_assert(kTileSlots >= 2 && kTileSlots <= 8, "slot | pixel takes 9 bits of 
 constexpr int kTileSlotsMulti = RT_TILE_SLOTS_MULTI;
 static_assert(kTileSlotsMulti >= 2 && kTileSlotsMulti <= 8, "slot | pixel takes 9 bits of a record's meta word");
 constexpr int kSlotHdr = 4;                                 // words: tx | ty << 16, frame, samples still to take (64 bits)
-constexpr int tile_slots(int out) { return out == 3 ? RT_TILE_SLOTS_MULTI_SMALL : out == 2 ? kTileSlotsMulti : kTileSlots; }
+constexpr int tile_slots(int out) { return out >= 3 ? RT_TILE_SLOTS_MULTI_SMALL : out == 2 ? kTileSlotsMulti : kTileSlots; }
 constexpr int slot_bytes(int out) {     // per wave: stage (RGBX words, or 3 float sums per pixel) + header (+ next record)
   return out == 0 ? 0 : out == 1 ? kTileSlots * (64 * 4 + kSlotHdr * 4) : tile_slots(out) * (3 * 64 * 4 + kSlotHdr * 4 + 72 * 2);
 }
@@ -1982,7 +1982,7 @@ __device__ __forceinline__ int meta_slotpix(uint32_t m) { return int((m >> 7) & 
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
 constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
-constexpr int ring_of(int out) { return out == 3 ? 1 : kRing; }   // (one entry costs the one-sample path 9 %; OUT = 3 buys a workgroup per CU with it)
+constexpr int ring_of(int out) { return out >= 3 ? 1 : kRing; }   // (one entry costs the one-sample path 9 %; OUT = 3 buys a workgroup per CU with it)
 #ifndef RT_CLAIM
 #define RT_CLAIM 32    // slots per claim at most: one occupancy word's worth
 #endif
@@ -2072,15 +2072,16 @@ void queue_take_back(float* qf, const float* src, int at) {
 // OUT: how finished pixels leave — 0: one by one (float / multi-sample / refraction paths), 1: whole tiles from
 // RGBX staging in per-wave tile slots, 2: the same with all samples of a pixel summed in the slot (MULTI), 3: MULTI
 // with three slots and one ring entry per wave — 40.4 KB of LDS per workgroup besides the spheres, so that scenes of up
-// to 36 spheres keep FOUR workgroups per CU (OUT = 2: six slots, three workgroups, 133 VGPRs)
+// to 36 spheres keep FOUR workgroups per CU (OUT = 2: six slots, three workgroups, 133 VGPRs), 4: the same as TWO
+// workgroups of eight waves, which share one copy of the spheres: scenes of up to 72 spheres (the 64-sphere target)
 // GRID: 0 = few spheres (bit tables), 1 = many spheres (grid or lists for reflection rays, lists for shadow rays), 2 = the
 // same as workgroups of EIGHT waves around one copy of the sphere list: from 513 spheres on a copy per four waves leaves
 // LDS for three workgroups per CU, one per eight waves for two of twice the size (config 4: 308 -> 334 Grays/s).
 // (Before that, 2 was the four-wave form compiled for three waves per SIMD — 156 VGPRs, nothing spilled: 271 -> 281.)
 // 3 = SIXTEEN waves around one copy (from ~1100 spheres on, where two eight-wave workgroups no longer fit a CU).
 template <int MODE, bool REFR, bool CUBES, int GRID = 0, int OUT = 0>
-__global__ __launch_bounds__((GRID == 3 ? 1024 : GRID == 2 ? 512 : kBlock), (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
-  constexpr int kThreads = GRID == 3 ? 1024 : GRID == 2 ? 512 : kBlock;
+__global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock), (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+  constexpr int kThreads = GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock;
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
   constexpr int kRing = ring_of(OUT);
@@ -3436,7 +3437,7 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false
 }
 template <int OUT>
 RenderKernel pick_slot_kernel(int rng_mode, bool cubes, int grid) {
-  if constexpr (OUT != 3) {   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
+  if constexpr (OUT < 3) {   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
     if constexpr (OUT == 1) {   // (OUT = 2 is compiled for three waves per SIMD as it is)
       if (grid == 3 && !cubes)
         return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 3, OUT>
@@ -3459,6 +3460,7 @@ RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, int grid = 
   if (out == 1 && !refr) return pick_slot_kernel<1>(rng_mode, cubes, grid);
   if (out == 2 && !refr) return pick_slot_kernel<2>(rng_mode, cubes, grid);
   if (out == 3 && !refr) return pick_slot_kernel<3>(rng_mode, cubes, 0);
+  if (out == 4 && !refr) return pick_slot_kernel<4>(rng_mode, cubes, 0);
   if (grid == 3 && !refr && !cubes)
     return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 3>
                                     : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 3>;
@@ -3584,6 +3586,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   if (slots == 2 && !listed && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3)) >
                                    workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 2)))
     slots = 3;
+  // ... or, up to 72 spheres, as two workgroups of eight waves around one copy of the spheres (the 64-sphere target scene)
+  if (slots == 2 && !listed && 2 * stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3, 8) <= size_t(160 * 1024)) {
+    slots = 4;
+    wg_waves = 8;
+  }
   const bool multi = slots >= 2;
   const size_t vis_need = size_t(((w.nx + 7) / 8) | 1) * size_t((w.n_rows + 7) / 8) * kVisTile * size_t(batch) *
                           size_t(multi ? samples : 1);   // whole 8x8 tiles, odd pitch; MULTI: a record per sample
@@ -3857,10 +3864,10 @@ int rt_create(int device_id, rt_ctx** out) {
       if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), g >= 2 ? size_t(160 * 1024) : big)) != hipSuccess ||
           (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), g >= 2 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
         return bail(e, "hipFuncSetAttribute");
-  for (int out = 1; out <= 3; ++out) {
-    const size_t bigs = stream_lds(RT_MAX_SPHERES, false, out);
+  for (int out = 1; out <= 4; ++out) {
+    const size_t bigs = out == 4 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, out);
     for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-      for (int v = 0; v < (out == 3 ? 2 : 3); ++v)   // plain, cubes, grid
+      for (int v = 0; v < (out >= 3 ? 2 : 3); ++v)   // plain, cubes, grid
         if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2 ? 1 : 0, out), bigs)) != hipSuccess)
           return bail(e, "hipFuncSetAttribute");
   }
