@@ -1800,8 +1800,11 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
 // 32 x 32 pixels with the defaults.  Before anything else the wave culls the scene against the cone of the WHOLE
 // region: most regions of a mostly-sky frame hold nothing, and such a region of a plain 8-bit frame leaves as 32
 // rows of black from one cone and one cull turn (a quarter of what its four blocks would spend to find out the same).
+// Six blocks (48 rows) per region: against four, +4.9 % on config 2, +4 % on config 5, +2.7 % on config 3, +3.6 % on the
+// glass and cube scenes, configs 1 and 4 and the 64-sphere target unchanged within 0.6 %.  Five: config 3 -6 %; seven:
+// config 1 -2 %; eight: config 1 -29 % (A/B in one call each; twelve measures like six on config 2, -1.4 % on config 1).
 #ifndef RT_VIS_ROWS
-#define RT_VIS_ROWS 4
+#define RT_VIS_ROWS 6
 #endif
 constexpr int kVisRows = RT_VIS_ROWS;
 template <int MODE, bool CUBES, bool MULTI = false, bool MANY = false>
