@@ -1806,14 +1806,21 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
 #ifndef RT_VIS_ROWS
 #define RT_VIS_ROWS 6
 #endif
+// Workgroups of TWO waves (two regions side by side): a workgroup's wave slots come free when its last wave ends, and most
+// regions are empty and over in ~100 instructions while a region with spheres in it runs six blocks of rays — with four
+// waves per workgroup the pass held 19 % of its wave slots.  Against 256 threads (all at six blocks): config 2 +1.1 %, the
+// 64-sphere target +4.7 %, config 3 +2.3 %, config 4 +1.9 %; 64 threads -5.7 % on config 2 (dispatch), 512 / 1024: -8.5 / -13 %.
+#ifndef RT_VIS_BLOCK
+#define RT_VIS_BLOCK 128
+#endif
 constexpr int kVisRows = RT_VIS_ROWS;
 template <int MODE, bool CUBES, bool MULTI = false, bool MANY = false>
-__global__ __launch_bounds__(kBlock, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
+__global__ __launch_bounds__(RT_VIS_BLOCK, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
   static_assert(!MANY || !CUBES, "the many-sphere form of the pass exists for scenes without cubes");
   constexpr int NT = kVisTiles;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * kVisRows);   // window coordinates
+  const int col0 = (int(blockIdx.y) * (RT_VIS_BLOCK / 64) + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * kVisRows);   // window coordinates
   if (p.nx - col0 <= 0) return;                           // wave-uniform: beyond the right edge
   constexpr bool region_kept = MANY;
   bool region_any = false;
@@ -3748,7 +3755,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       p.sample_index = s;
       if (stream_kernel) {
         // one wave per pair of 8x8 tiles, 8 tiles (64 x 8 pixels) per workgroup; tile rows go in x (no 65535 limit)
-        const dim3 vgrid(unsigned((w.n_rows + 8 * kVisRows - 1) / (8 * kVisRows)), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf));
+        const dim3 vgrid(unsigned((w.n_rows + 8 * kVisRows - 1) / (8 * kVisRows)), unsigned((w.nx + 8 * kVisTiles * (RT_VIS_BLOCK / 64) - 1) / (8 * kVisTiles * (RT_VIS_BLOCK / 64))), unsigned(nf));
         const size_t vlds = 0;
         ctx->host_primaries += (unsigned long long)win_px * (unsigned long long)nf;   // one primary ray per pixel and sample
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
@@ -3762,7 +3769,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         // (work counters and occupancy bits start every launch at zero — also those in the scratch array, which
         // keeps the last call's contents)
         if (!multi || s == 0) RT_HIP(ctx, hipMemsetAsync(d_chunk, 0, chunk_need, ctx->stream));
-        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi, ctx->n_spheres > 64), vgrid, dim3(kBlock), vlds, ctx->stream, p);
+        hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi, ctx->n_spheres > 64), vgrid, dim3(RT_VIS_BLOCK), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples)
           hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, list_kernel, slots), sgrid, dim3(threads), lds, ctx->stream, p);
