@@ -48,9 +48,9 @@ PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 
 # (TCC_EA0_WRREQ x 64 + TCC_EA0_RDREQ x 64 x 2, the guide's gfx950 correction), and the rays of that launch pair.
 # (tools/pmc_constants.py prints these lines from a tools/profile.sh directory.)
 PMC = {
-    "c2": dict(profile="profiles/r2z_c2_rt_{stream,visibility}_kernel.txt", flops=3.929e+11, valu=8.511e+09, salu=3.373e+09, hbm_bytes=1.121e+10, rays=7.863e+09),
-    "t64": dict(profile="profiles/r2z_t64_rt_{stream,visibility}_kernel.txt", flops=3.472e+11, valu=7.693e+09, salu=3.104e+09, hbm_bytes=1.186e+10, rays=6.428e+09),
-    "c4": dict(profile="profiles/r2z_c4_rt_{stream,visibility}_kernel.txt", flops=3.41e+11, valu=6.572e+09, salu=1.862e+09, hbm_bytes=1.248e+10, rays=3.36e+09),
+    "c2": dict(profile="profiles/r2z_c2_rt_{stream,visibility}_kernel.txt", flops=3.929e+11, valu=8.509e+09, salu=3.375e+09, hbm_bytes=1.136e+10, rays=7.863e+09),
+    "t64": dict(profile="profiles/r2z_t64_rt_{stream,visibility}_kernel.txt", flops=3.472e+11, valu=7.691e+09, salu=3.105e+09, hbm_bytes=1.207e+10, rays=6.428e+09),
+    "c4": dict(profile="profiles/r2z_c4_rt_{stream,visibility}_kernel.txt", flops=3.41e+11, valu=6.572e+09, salu=1.862e+09, hbm_bytes=1.283e+10, rays=3.36e+09),
 }
 
 WORKLOADS = {
