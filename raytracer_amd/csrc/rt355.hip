@@ -3036,26 +3036,37 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(const RenderParams p) {
 // The same for the tiles the visibility pass marked occupied only (RenderParams::defer_sparse: refractive scenes at one
 // sample per pixel, 8-bit frames): every other tile is black already, and only these tiles' sums were ever cleared or
 // added to — on a mostly empty frame a fifth of the 12 + 3 bytes per pixel that clearing and resolving everything moves.
-// One wave per four tiles side by side, as in the visibility pass; whole tiles leave as dwords (store_tile8).
-__global__ __launch_bounds__(256) void rt_resolve_tiles_kernel(const RenderParams p) {
-  constexpr int NT = kVisTiles;
+// One wave per region of the visibility pass (kVisRows blocks of four tiles): lane t looks up the occupancy bit of tile
+// t, one ballot says which tiles there are, and the wave walks those — an empty region costs one load and one ballot
+// (with a wave per block and a dependent load per tile the kernel took 3.2 ms per 1024 frames of refractive_scene()).
+// Whole tiles leave as dwords (store_tile8).
+__global__ __launch_bounds__(128) void rt_resolve_tiles_kernel(const RenderParams p) {
+  constexpr int NT = kVisTiles, R = kVisRows;
+  static_assert(NT == 4 && NT * R <= 64, "lane t: tile t % 4 of block t / 4");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * 4 + wave) * (8 * NT), row0 = int(blockIdx.x) * 8;
+  const int col0 = (int(blockIdx.y) * 2 + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * R);
   if (p.nx - col0 <= 0) return;
   const int lx = lane & 7, ly = lane >> 3;
-  const int rows = min(8, p.n_rows - row0);
   const long long frame_px = (long long)frame * p.frame_stride_px, accum_px = (long long)frame * p.accum_stride_px;
   uint8_t* out = p.out_rgb + frame_px * 3;
   const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
-  const uint32_t id0 = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
-                       uint32_t(col0 >> 3);
-#pragma unroll
-  for (int q = 0; q < NT; ++q) {
-    const int cols = min(8, p.nx - col0 - 8 * q);
-    if (cols <= 0) break;
-    const uint32_t id = id0 + uint32_t(q), slot = id / kTileCounters, h = id % kTileCounters;
-    if (!((p.occ[size_t(h) * size_t(p.occ_words) + (slot >> 5)] >> (slot & 31u)) & 1u)) continue;   // wave-uniform
+  bool there = false;
+  {
+    const int q = lane & 3, row0 = rowR + 8 * (lane >> 2);
+    if (lane < NT * R && row0 < p.n_rows && p.nx - col0 - 8 * q > 0) {
+      const uint32_t id = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
+                          uint32_t(col0 >> 3) + uint32_t(q);
+      const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
+      there = (p.occ[size_t(h) * size_t(p.occ_words) + (slot >> 5)] >> (slot & 31u)) & 1u;
+    }
+  }
+  unsigned long long todo = __ballot(there);
+  while (todo != 0ull) {
+    const int t = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const int q = t & 3, row0 = rowR + 8 * (t >> 2);
+    const int rows = min(8, p.n_rows - row0), cols = min(8, p.nx - col0 - 8 * q);
     uint32_t rgbx = 0u;
     if (lx < cols && ly < rows) {
       const float* a = p.accum + (accum_px + (long long)(row0 + ly) * p.nx + (col0 + 8 * q + lx)) * 3;
@@ -3775,8 +3786,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
           hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, list_kernel, slots), sgrid, dim3(threads), lds, ctx->stream, p);
         if (refr && s + 1 == samples) {   // (never MULTI)
           if (p.defer_sparse)
-            hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 7) / 8), unsigned((w.nx + 32 * kVisTiles - 1) / (32 * kVisTiles)), unsigned(nf)),
-                               dim3(256), 0, ctx->stream, p);
+            hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 8 * kVisRows - 1) / (8 * kVisRows)), unsigned((w.nx + 16 * kVisTiles - 1) / (16 * kVisTiles)), unsigned(nf)),
+                               dim3(128), 0, ctx->stream, p);
           else
             hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
                                ctx->stream, p);
