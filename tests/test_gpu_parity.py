@@ -189,7 +189,7 @@ def test_refraction_against_reference_goldens(renderer, name):
 
 
 @pytest.mark.parametrize("w,h,D,spp,mode", [(320, 240, 5, 1, "K"), (333, 187, 5, 2, "K"), (160, 120, 2, 1, "C"),
-                                            (640, 480, 8, 1, "K")])
+                                            (640, 480, 8, 1, "K"), (333, 187, 4, 1, "K"), (1000, 52, 3, 1, "K")])
 def test_refraction_against_oracle(renderer, oracle, w, h, D, spp, mode):
     """compute_refraction (raytracer.py:213-230, :252-254) — both children of a
     hit are followed — and the shadow rule "blocked only by an opaque nearest hit" (:187, :202)."""
