@@ -135,9 +135,11 @@ def test_float_colour_accuracy(renderer):
 @pytest.mark.parametrize("w,h,n,seed,D,ns,spp", [
     (480, 270, 8, 1, 5, 12, 1), (480, 270, 64, 2, 8, 12, 1), (333, 187, 64, 2, 5, 12, 2),
     (320, 180, 1024, 3, 3, 12, 1), (200, 120, 8, 1, 5, 4, 1), (200, 120, 8, 1, 5, 1, 1),
-    (200, 120, 8, 1, 5, 16, 1), (200, 120, 8, 1, 5, 30, 1), (37, 19, 3, 0, 5, 12, 3), (1, 1, 8, 1, 5, 12, 1)])
+    (200, 120, 8, 1, 5, 16, 1), (200, 120, 8, 1, 5, 30, 1), (37, 19, 3, 0, 5, 12, 3), (1, 1, 8, 1, 5, 12, 1),
+    (328, 203, 400, 4, 4, 12, 1), (328, 203, 700, 5, 4, 12, 1), (250, 131, 2000, 6, 3, 12, 1), (333, 187, 300, 7, 4, 12, 2)])
 def test_full_frames_against_live_oracle(renderer, oracle, w, h, n, seed, D, ns, spp):
-    """Whole frames (ragged sizes, other area-light sample counts, 1024 spheres) vs the oracle."""
+    """Whole frames (ragged sizes, other area-light sample counts, 1024 spheres) vs the oracle; 300 .. 2000 spheres: the
+    list kernels in their four-, eight- and sixteen-wave workgroups and the many-sphere form of the visibility pass."""
     scene = default_scene() if n == 3 else generate_scene(n, seed, 1920, 1080, keep_default=(n == 8))
     scene["area_light"].samples = ns
     renderer.upload_scene(scene)
