@@ -3,9 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|t64|c3|c1|c4|c5|refr|cubes|cubes_glass]
 
-One "step" = one batch of ``--frames`` (default 1024, = one kernel launch pair) 1080p frames of BASELINE.json config 2
-(1920x1080, 8-sphere scene, depth 5, 13 shadow rays per shaded hit, keyed RNG, seed = frame
-index), inputs (scene) already resident on the GPU.  With N > 1 ranks (one process per GPU,
+One "step" = ``--batches`` (default 10) batches of ``--frames`` (default 1024, = one kernel launch pair) 1080p frames of
+BASELINE.json config 2 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per shaded hit, keyed RNG, seed = frame
+index), inputs (scene) already resident on the GPU: 10 240 frames, ~125 ms per step, so that the default 20 timed steps
+last ~2.5 s and the clocks are at their steady state (a single batch takes 12 ms).  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
 (tile t -> rank t mod N), each rank renders its tiles of all frames of the batch, and ONE RCCL
 gather per step moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
@@ -17,12 +18,15 @@ modelled.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — FP32-VALU roofline of the launch pair rt_visibility_kernel + rt_stream_kernel (one
-                 pair per batch: primary rays / everything after them).  `achieved` / `frac` are the ALGORITHMIC
-                 flops of the reference's brute-force algorithm over the pair's live HIP-event
-                 duration: a speed-of-algorithm figure, not VALU utilisation (the kernels cull most of that work).
-                 `executed_frac` (FP32 flops the VALUs executed / peak) and `issue_frac` (vector + scalar
-                 wave-instructions / issue slots) say what the hardware did: per-ray PMC counts from the committed
-                 rocprofv3 pass named in `pmc_profile`, scaled by this run's rays and divided by this run's time;
+                 pair per batch: primary rays / everything after them).  `achieved` / `frac` are what the hardware
+                 EXECUTED: FP32 flops the VALUs retired (per-ray PMC counts from the committed rocprofv3 pass named in
+                 `pmc_profile`, scaled by this run's rays) over the pair's live HIP-event duration, against the 157.3
+                 TFLOP/s peak — never above 1.  `issue_frac` = vector + scalar wave-instructions / issue slots.
+                 `algorithmic_achieved` / `algorithmic_frac` price the flops of the reference's brute-force algorithm
+                  over the same time: a speed-of-algorithm figure that exceeds 1 where the kernels cull
+                 most of that work — it says how fast the ALGORITHM runs, not how busy the VALUs are;
+  single_frame — the drop-in call itself, render(1920, 1080) -> numpy array (raytracer.py:310 renders ONE frame): scene
+                 check, one launch pair, copy of the frame to the host; ms per call and the Mrays/s that makes;
   target_64sph — the same measurement, shorter, on the north-star target scene (1080p, depth 5, 64 spheres);
   cpu_baseline — the FP64 C++ restatement of the reference (oracle/, "port") timed on this
                  host's cores on a bounded number of whole frames of the same workload (rank 0, N = 1 only).
@@ -136,18 +140,48 @@ def cpu_baseline(wl, target_s=5.0):
                 python_reference_mrays_1core=PY_REFERENCE_MRAYS)
 
 
+def single_frame(r, wl):
+    """The reference's API renders ONE frame (raytracer.py:310): time the drop-in call — scene check (an unchanged scene is
+    not uploaded again), one launch pair for one frame, copy of the frame to a pinned host array."""
+    import raytracer_amd
+    from raytracer_amd import render as render_mod
+    w, h, _, _, _, D, _ = WORKLOADS[wl]
+    scene = build_scene(wl)
+    saved = render_mod.scene
+    render_mod.scene = scene
+    try:
+        for i in range(5):
+            raytracer_amd.render(w, h, 1, max_depth=D, seed=i)
+        rr = render_mod._renderer(None)
+        rr.reset_ray_counts()
+        n = 50
+        t0 = time.perf_counter()
+        for i in range(n):
+            img = raytracer_amd.render(w, h, 1, max_depth=D, seed=i)
+        dt = time.perf_counter() - t0
+        rays = rr.ray_counts()["total"]
+    finally:
+        render_mod.scene = saved
+    assert img.shape == (h, w, 3)
+    return {"ms_per_call": dt / n * 1e3, "mrays_per_s": rays / dt / 1e6, "calls": n,
+            "what": f"raytracer_amd.render({w}, {h}) -> numpy uint8 [H, W, 3] on the host, one call after another "
+                    "(scene check, one launch pair, device-to-host copy of the frame)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=1024, help="frames per step (batch)")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per batch (one kernel launch pair)")
+    ap.add_argument("--batches", type=int, default=10, help="batches per step")
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--kernel", default="stream", choices=["stream", "pixel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target", action="store_true", help="skip the second timed region on the 64-sphere target scene")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the timing of the one-frame drop-in call")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     args = ap.parse_args()
 
@@ -164,17 +198,21 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: rt355 has no CPU path")
     # RT_BENCH_BACKEND=gloo rehearses the N > 1 code path with all ranks on the GPUs that exist (slabs are
-    # staged through host memory); the driver's runs use nccl = RCCL, one rank per GPU
+    # staged through host memory); the driver's runs use nccl = RCCL, one rank per GPU.
+    # RT_BENCH_FORCE_EXCHANGE=1 at N = 1: the whole N > 1 step — compaction, count exchange, gather, placement, every
+    # collective through RCCL — as a group of ONE rank (the rehearsal a one-GPU box allows).
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    force_exchange = bool(os.environ.get("RT_BENCH_FORCE_EXCHANGE"))
     if backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         if backend == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     from raytracer_amd import tiling
     from raytracer_amd._lib import FRAMES_PER_LAUNCH
@@ -192,8 +230,9 @@ def main():
         r.set_tile_flush(False)
     buffers = {}                                # frame / exchange buffers, reused by workloads of the same size
 
-    def measure(wl, F, steps, warmup, samples):
-        """warmup + `steps` timed steps of workload `wl`; returns the numbers of the JSON line (rank 0) or None."""
+    def measure(wl, F, B, steps, warmup, samples):
+        """warmup + `steps` timed steps (of B batches of F frames) of workload `wl`; returns the numbers of the JSON line
+        (rank 0) or None."""
         w, h, n_sph, _, _, D, desc = WORKLOADS[wl]
         tr = args.tile_rows
         packed = pack_scene(build_scene(wl))
@@ -208,11 +247,11 @@ def main():
             if rank == 0 or frame_parallel:
                 n_local = len(frames_of_rank(F, rank, world)) if frame_parallel else F
                 buffers["frames_out"] = torch.empty((n_local, h, w, 3), dtype=torch.uint8, device=dev)
-            # N > 1: every rank renders its row tiles of the F frames of a step into a slab; one gather per step
+            # N > 1: every rank renders its row tiles of the F frames of a batch into a slab; one gather per batch
             # moves the occupied tiles of the slabs to GPU 0, where one pass writes the frames in image order.
-            # Pipelined: compaction, gather and placement of earlier steps overlap the render of later ones, and no
+            # Pipelined: compaction, gather and placement of earlier batches overlap the render of later ones, and no
             # rank's host waits for its own render (BatchExchange).  RT_BENCH_DENSE=1 sends whole slabs.
-            use_ex = (world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE")) and not frame_parallel   # (env: rehearse on 1 GPU)
+            use_ex = (world > 1 or force_exchange) and not frame_parallel
             if use_ex:
                 fo = buffers.get("frames_out")
                 if os.environ.get("RT_BENCH_DENSE"):
@@ -222,9 +261,12 @@ def main():
                     table = {}
 
                     def place_tiles(entries, counts, i):
-                        table["t"] = r.place_tiles(entries, counts, w, h, tr, fo, table.get("t"))
+                        # (RCCL: called with the exchange's side stream current — the placement runs beside later renders)
+                        table["t"] = r.place_tiles(entries, counts, w, h, tr, fo, table.get("t"),
+                                                   on_current_stream=buffers["ex"].on_side)
                     buffers["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
-                                                  capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8))
+                                                  capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
+                                                  force_collectives=force_exchange)
         ex = buffers.get("ex")
         frames_out = buffers.get("frames_out")
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -238,23 +280,25 @@ def main():
         cams = r.pack_cameras(cams)                 # packed once: the step loop must not be host-bound at N = 8
 
         def step(i, timed_idx=None):
-            if timed_idx is not None:
-                ev[timed_idx][0].record()
-            if frame_parallel:                      # this rank's frames of the batch, whole
-                r.render_frames(cams, [i * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=frames_out)
-            else:
-                # N = 1: the rank owns every row, so its packed slab IS the frame batch
-                out = frames_out if ex is None else ex.slab(i).view(F, rows_max, w, 3)
-                r.render_frames(cams, range(i * F, (i + 1) * F), w, h, samples, max_depth=D, rng_mode="K",
-                                out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
-            if timed_idx is not None:
-                ev[timed_idx][1].record()
-            if ex is not None:
-                ex.submit(i)
+            for b in range(B):                      # batch number j: its frames are j F .. (j + 1) F - 1 of the run
+                j = i * B + b
+                if timed_idx is not None and b == 0:
+                    ev[timed_idx][0].record()
+                if frame_parallel:                  # this rank's frames of the batch, whole
+                    r.render_frames(cams, [j * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=frames_out)
+                else:
+                    # N = 1: the rank owns every row, so its packed slab IS the frame batch
+                    out = frames_out if ex is None else ex.slab(j).view(F, rows_max, w, 3)
+                    r.render_frames(cams, range(j * F, (j + 1) * F), w, h, samples, max_depth=D, rng_mode="K",
+                                    out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
+                if timed_idx is not None and b == B - 1:
+                    ev[timed_idx][1].record()
+                if ex is not None:
+                    ex.submit(j)
 
         def barrier():
             if ex is not None:
-                ex.drain()         # the last steps' gathers and placements belong to the timed region
+                ex.drain()         # the last batches' gathers and placements belong to the timed region
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -284,12 +328,16 @@ def main():
         rc = r.ray_counts()
         stats = torch.tensor([rc["total"], rc["shaded_hits"], rc["primary"]], dtype=torch.float64, device=red_dev)
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        # (refractive scenes: as many frames per launch pair as fit 32 GiB of float pixel sums, kRefrSumBytes in csrc/rt355.hip)
-        per_launch = min(FRAMES_PER_LAUNCH, max(1, (32 << 30) // (12 * rows_max * w))) if packed.has_refraction else FRAMES_PER_LAUNCH
+        # (refractive scenes whose pixel sums lie in device memory — several samples per pixel —: as many frames per launch
+        # pair as fit 32 GiB of them, kRefrSumBytes in csrc/rt355.hip)
+        refr_slabs = packed.has_refraction and (samples != 1 or os.environ.get("RT_BENCH_NO_TILE_FLUSH"))
+        per_launch = min(FRAMES_PER_LAUNCH, max(1, (32 << 30) // (12 * rows_max * w))) if refr_slabs else FRAMES_PER_LAUNCH
         n_local_frames = len(mine) if frame_parallel else F
         one_stream_launch = samples == 1 or (2 <= samples <= 64 and not packed.has_refraction and args.kernel == "stream"
                                              and not os.environ.get("RT_BENCH_NO_TILE_FLUSH"))
-        launches_per_step = -(-n_local_frames // per_launch) * (1 if one_stream_launch else samples)
+        launches_per_step = B * -(-n_local_frames // per_launch) * (1 if one_stream_launch else samples)
+        # (with several batches per step the events also cover the other stream-ordered work between the pairs: the
+        # exchange's compaction kernels at N > 1)
         kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (steps * launches_per_step)
         kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
         if world > 1:
@@ -301,64 +349,75 @@ def main():
         total_rays, shaded, primary = (float(x) for x in stats.tolist())
         dt = float(tmax.item())
         launches = steps * launches_per_step
+        secs = kern_ms * 1e-3
         # per-launch (per rank) algorithmic flops of the launch pair on rank 0
         fl = algorithmic_flops(rc["total"], rc["shaded_hits"], n_sph, packed.area_samples) / launches
-        achieved = fl / (kern_ms * 1e-3) / 1e12
-        roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_TFLOPS,
-                "frac_is": "ALGORITHMIC: flops of the reference's brute-force algorithm (rays*(5+17N) + shaded*(55+75*(1+ns)), "
-                           "SURVEY.md 8d) per second / FP32 VALU peak - a speed-of-algorithm figure that exceeds 1 on many-sphere "
-                           "scenes because the kernels cull most of that work; VALU utilisation is executed_frac / issue_frac",
-                "traffic": None, "executed_frac": None, "issue_frac": None, "pmc_profile": None,
+        roof = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                "frac_is": "EXECUTED: FP32 flops the VALUs retired (PMC SQ_INSTS_VALU_{ADD,MUL,TRANS}_F32 + 2 x FMA_F32, x 64 lanes: "
+                           "a full-wave upper bound; per-ray counts of the committed profile `pmc_profile` of this workload, scaled "
+                           "by this run's rays) / this run's launch-pair time / 157.3 TFLOP/s.  null where no profile of the "
+                           "workload is committed",
+                "traffic": None, "issue_frac": None, "pmc_profile": None,
                 "kernel": ("rt_visibility_kernel + rt_stream_kernel (one pair per launch; the events also cover the ~4 us "
                            "rt_camera_table_kernel, up to 16 frame-record stores and a 4 MB memset)")
                 if args.kernel == "stream" else "rt_pixel_kernel",
-                "kernel_ms": kern_ms, "flops_per_launch": fl}
+                "kernel_ms": kern_ms, "launches_per_step": launches_per_step,
+                "algorithmic_flops_per_launch": fl, "algorithmic_achieved": fl / secs / 1e12,
+                "algorithmic_frac": fl / secs / 1e12 / PEAK_FP32_TFLOPS,
+                "algorithmic_is": "flops of the reference's brute-force algorithm (rays*(5+17N) + shaded*(55+75*(1+ns)), SURVEY.md "
+                                  "8d) / time / peak: a speed-of-algorithm figure, above 1 where the kernels cull most of that work"}
         pmc = PMC.get(wl)
         if pmc and samples == 1 and args.kernel == "stream" and not os.environ.get("RT_BENCH_NO_TILE_FLUSH"):
             # what the hardware executed: the profiled launch pair's counts per ray x this run's rays per launch
             scale = (rc["total"] / launches) / pmc["rays"]
-            secs = kern_ms * 1e-3
-            roof["executed_frac"] = pmc["flops"] * scale / secs / 1e12 / PEAK_FP32_TFLOPS
+            roof["achieved"] = pmc["flops"] * scale / secs / 1e12
+            roof["frac"] = roof["achieved"] / PEAK_FP32_TFLOPS
+            roof["executed_flops_per_launch"] = pmc["flops"] * scale
             roof["issue_frac"] = (pmc["valu"] + pmc["salu"]) * scale / secs / ISSUE_SLOTS_PER_S
             roof["valu_issue_frac"] = pmc["valu"] * scale / secs / ISSUE_SLOTS_PER_S
             roof["traffic"] = pmc["hbm_bytes"] * scale
+            roof["frame_bytes_per_launch"] = float(n_local_frames) * rows_max * w * 3
             roof["pmc_profile"] = pmc["profile"]
-            roof["pmc_note"] = ("executed_frac = FP32 flops the VALUs executed (PMC SQ_INSTS_VALU_*_F32, full-wave upper bound) / s / "
-                                "157.3 TFLOP/s; issue_frac = (vector + scalar wave-instructions) / (1024 SIMDs x 1.2e9 issue "
-                                "slots/s: one wave64 instruction per 2 clocks); traffic = HBM bytes per launch pair (TCC_EA0_*); "
-                                "PMC counts per ray from the named profile of this workload, scaled by this run's rays")
+            roof["pmc_note"] = ("issue_frac = (vector + scalar wave-instructions) / (1024 SIMDs x 1.2e9 issue slots/s: one wave64 "
+                                "instruction per 2 clocks); traffic = HBM bytes per launch pair (TCC_EA0_*); PMC counts per ray from "
+                                "the named profile of this workload, scaled by this run's rays")
         if frame_parallel:
             par = f"frame-parallel x{world}: frame f -> rank f mod {world}, whole frames, one gather after the timed region"
-        elif world > 1:
+        elif world > 1 or ex is not None:
             par = f"row-tiles x{world} (tile {tr} rows) + RCCL gather to GPU 0" + \
-                  (" of the occupied 8x8 tiles" if ex is not None and ex.sparse else "")
+                  (" of the occupied 8x8 tiles" if ex is not None and ex.sparse else "") + \
+                  (" (a group of ONE rank: rehearsal of the N > 1 step)" if world == 1 else "")
         else:
             par = "single GPU"
         out = {
             "value": total_rays / dt / 1e6,
             "ms_per_step": dt / steps * 1e3,
-            "config": {"workload": f"{desc}; batch of {F} frames per step, {samples} spp, "
+            "config": {"workload": f"{desc}; step = {B} batches of {F} frames (one launch pair each), {samples} spp, "
                                    f"keyed RNG, {n_sph} spheres, 12 area-light samples",
-                       "width": w, "height": h, "max_depth": D, "frames_per_step": F, "parallelism": par},
-            "rays_per_frame": total_rays / (steps * F),
+                       "width": w, "height": h, "max_depth": D, "frames_per_batch": F, "batches_per_step": B,
+                       "frames_per_step": F * B, "parallelism": par},
+            "rays_per_frame": total_rays / (steps * F * B),
             "rays_per_pixel": total_rays / max(primary, 1.0),
             "mpixels_per_s": primary / dt / 1e6,
-            "frames_per_s": steps * F / dt,
+            "frames_per_s": steps * F * B / dt,
+            "timed_region_s": dt,
             "exchange_bytes_per_step_rank0": (ex.sent_bytes / steps) if ex is not None else 0,
             "roofline": roof,
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
-            out["final_gather_note"] = (f"one gather of the last step's {F} frames to GPU 0 after the timed region; "
+            out["final_gather_note"] = (f"one gather of the last batch's {F} frames to GPU 0 after the timed region; "
                                         "frames_per_s is at render completion (SURVEY.md 8e)")
         return out
 
-    res = measure(args.workload, args.frames, args.steps, args.warmup, args.samples)
+    res = measure(args.workload, args.frames, args.batches, args.steps, args.warmup, args.samples)
     target = None
     if not args.no_target and args.workload != "t64":
-        # the north-star target scene (1080p, depth 5, 64 spheres), same frames per step, a shorter region
-        target = measure("t64", args.frames, max(2, min(args.steps, 6)), 1, 1)
+        # the north-star target scene (1080p, depth 5, 64 spheres): the same step, the same number of steps
+        target = measure("t64", args.frames, args.batches, args.steps, 1, 1)
+    single = None
+    if rank == 0 and world == 1 and not args.no_single_frame and args.kernel == "stream":
+        single = single_frame(r, args.workload)
 
     if rank == 0:
         out = {
@@ -378,13 +437,15 @@ def main():
             tr_ = target["roofline"]
             out["target_64sph"] = {"value": target["value"], "unit": "Mrays/s", "ms_per_step": target["ms_per_step"],
                                    "workload": target["config"]["workload"], "kernel_ms": tr_["kernel_ms"],
-                                   "algorithmic_frac": tr_["frac"], "executed_frac": tr_["executed_frac"],
+                                   "frac": tr_["frac"], "algorithmic_frac": tr_["algorithmic_frac"],
                                    "issue_frac": tr_["issue_frac"], "pmc_profile": tr_["pmc_profile"],
-                                   "frames_per_s": target["frames_per_s"]}
+                                   "frames_per_s": target["frames_per_s"], "timed_region_s": target["timed_region_s"]}
+        if single is not None:
+            out["single_frame"] = single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     r.close()

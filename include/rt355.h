@@ -191,8 +191,9 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samp
  * context on, held until the process ends), so it calls no hipMalloc / hipFree / allocating routine.  A frame
  * whose records do not fit — 2.25 bytes per pixel; 3840x2160 fits — is refused with RT_EINVAL and a message.
  * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two contexts, or two streams)
- * race; calls on one stream are ordered.  The scene must have been uploaded before (rt_upload_scene allocates
- * nothing on the device either, but synchronises). */
+ * race; calls on one stream are ordered.  The scene must have been uploaded before: rt_upload_scene, rt_set_refraction
+ * and rt_set_cubes are NOT allocation-free (they synchronise, and grow the scene's tables — shadow-candidate lists,
+ * direction table — with hipMalloc / hipFree when a scene needs more room than the last one). */
 int rt_render_noalloc(rt_ctx* ctx, const rt_camera* cam, int width, int height, int samples,
                       int max_depth, int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit);
 

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1982,7 +1983,10 @@ constexpr int kBounceCap = 128;                       // <= 63 records when a ti
 constexpr int kQueueFields = 15;     // P(3) D(3) T(3) acc(3) pixel(1) level|frame|sphere(1) pixel key(1)
 constexpr int kQueueFieldsSlots = 14; // tile slots: the pixel is a slot and a position in it, part of the meta word
 constexpr int kQueueFieldsRefr = 12; // refraction: no acc (nodes add into the pixel sums); pixel, meta and key are fields 9..11
-constexpr int queue_fields(bool refr, int out = 0) { return refr ? kQueueFieldsRefr : out ? kQueueFieldsSlots : kQueueFields; }
+constexpr int kQueueFieldsRefrSlots = 11; // ... with tile slots (the pixel is a slot and a position in it): meta and key are fields 9, 10
+constexpr int queue_fields(bool refr, int out = 0) {
+  return refr ? (out ? kQueueFieldsRefrSlots : kQueueFieldsRefr) : out ? kQueueFieldsSlots : kQueueFields;
+}
 // Tile slots (SLOTS variant of the stream kernel): the pixels of a tile leave together.  Finished pixels are
 // staged in LDS, one RGBX word each, in one of kTileSlots records per wave; when the last hit pixel of a tile
 // has finished, the wave stores the tile as the visibility pass stores an empty one (store_tile8: whole dwords,
@@ -2006,9 +2010,27 @@ static_assert(kTileSlots >= 2 && kTileSlots <= 8, "slot | pixel takes 9 bits of 
 constexpr int kTileSlotsMulti = RT_TILE_SLOTS_MULTI;
 static_assert(kTileSlotsMulti >= 2 && kTileSlotsMulti <= 8, "slot | pixel takes 9 bits of a record's meta word");
 constexpr int kSlotHdr = 4;                                 // words: tx | ty << 16, frame, samples still to take (64 bits)
-constexpr int tile_slots(int out) { return out >= 3 ? RT_TILE_SLOTS_MULTI_SMALL : out == 2 ? kTileSlotsMulti : kTileSlots; }
-constexpr int slot_bytes(int out) {     // per wave: stage (RGBX words, or 3 float sums per pixel) + header (+ next record)
-  return out == 0 ? 0 : out == 1 ? kTileSlots * (64 * 4 + kSlotHdr * 4) : tile_slots(out) * (3 * 64 * 4 + kSlotHdr * 4 + 72 * 2);
+// Refractive scenes (REFR with tile slots): a hit has two children, so a pixel is a TREE of records that end in different
+// passes.  All of them stay in the wave that took the tile in (queue and spill stack are per wave), so the tile's slot
+// holds three SUMS per pixel that every node of the tree adds its share to, and a count of the tile's records still
+// alive (16 bits per slot) instead of a count of unfinished pixels.  The sums are 32-bit FIXED-POINT (24 fractional
+// bits, LDS integer atomics, saturating): integer addition is associative, so a pixel's bytes depend on its tree alone
+// — not on the order in which the passes happened to reach its nodes, which varies with the work distribution from run
+// to run and from tiling to tiling (float atomics into a slab in device memory, the earlier form, gave neither
+// repeatable bytes nor acceptable write traffic: 22 x the frame's bytes on glass cubes).
+#ifndef RT_TILE_SLOTS_REFR
+#define RT_TILE_SLOTS_REFR 4
+#endif
+constexpr int kTileSlotsRefr = RT_TILE_SLOTS_REFR;
+static_assert(kTileSlotsRefr >= 2 && kTileSlotsRefr <= 4, "four 16-bit record counts in one scalar register pair");
+constexpr float kSumScale = 16777216.0f;                    // 2^24: a sum saturates at 256 (x samples <= 64: the mean still clamps to 1)
+constexpr int tile_slots(int out, bool refr = false) {
+  return refr ? kTileSlotsRefr : out >= 3 ? RT_TILE_SLOTS_MULTI_SMALL : out == 2 ? kTileSlotsMulti : kTileSlots;
+}
+constexpr int slot_bytes(int out, bool refr = false) {     // per wave: stage (RGBX words, or 3 sums per pixel) + header (+ next record)
+  return out == 0 ? 0
+       : refr ? kTileSlotsRefr * (3 * 64 * 4 + kSlotHdr * 4 + (out >= 2 ? 72 * 2 : 0))
+       : out == 1 ? kTileSlots * (64 * 4 + kSlotHdr * 4) : tile_slots(out) * (3 * 64 * 4 + kSlotHdr * 4 + 72 * 2);
 }
 // meta word of a SLOTS record: level (7 bits) | slot * 64 + pixel (9 bits) | object (12 bits, from bit 20)
 __device__ __forceinline__ uint32_t pack_meta_slot(int level, int slotpix, int object) {
@@ -2033,9 +2055,8 @@ constexpr int kClaimMax = RT_CLAIM;
 
 constexpr int kBounceCapRefr = 192;                   // refraction: RT_MAX_DEPTH + 2 x 64, see the pass sizing in the kernel
 // Refraction: the fields a record carries (no acc: nodes add into the pixel sums), in the order they are set aside
-constexpr int kSpillFields = 12;
-__host__ __device__ constexpr int spill_field(int k) { return k; }   // all kQueueFieldsRefr fields of a record
-static_assert(kSpillFields == kQueueFieldsRefr, "a spill block holds whole records");
+constexpr int kSpillFields = 12;                     // (the most: a block holds whole records of 11 or 12 fields)
+static_assert(kSpillFields == kQueueFieldsRefr && kQueueFieldsRefrSlots <= kSpillFields, "a spill block holds whole records");
 constexpr int kSpillBlocksMax = 32;                   // blocks of 64 records a wave may have set aside (3 KB each)
 template <int CAP>
 struct Queue {
@@ -2043,7 +2064,7 @@ struct Queue {
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
 constexpr int wave_lds_bytes(bool refr, int out = 0) {
-  return queue_fields(refr, out) * (refr ? kBounceCapRefr : kBounceCap) * 4 + ring_of(out) * kVisTile * 2 + slot_bytes(out);
+  return queue_fields(refr, out) * (refr ? kBounceCapRefr : kBounceCap) * 4 + ring_of(out) * kVisTile * 2 + slot_bytes(out, refr);
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -2057,54 +2078,27 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // set b
   return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
 
-#ifndef RT_SPILL_VARIANT
-#define RT_SPILL_VARIANT 0
-#endif
 // Refraction: the bottom 64 records of a wave's queue go to its spill block `dst`, the rest moves down
 // (lane l touches positions l, 64 + l and 128 + l only: no ordering between lanes is needed)
-template <int CAP>
-#if RT_SPILL_VARIANT == 1
-__device__ __noinline__
-#else
-__device__ __forceinline__
-#endif
-void queue_set_aside(float* qf, float* dst, int lane, int n) {
+template <int CAP, int FIELDS>
+__device__ __forceinline__ void queue_set_aside(float* qf, float* dst, int lane, int n) {
   Queue<CAP> q{qf};
   const bool row2 = 128 + lane < n;
-#if RT_SPILL_VARIANT == 3
-#pragma nounroll
-#else
 #pragma unroll
-#endif
-  for (int k = 0; k < kSpillFields; ++k) {
-    const int f = spill_field(k);
-    dst[k * 64] = q.at(f, lane);
+  for (int f = 0; f < FIELDS; ++f) {
+    dst[f * 64] = q.at(f, lane);
     const float a = q.at(f, 64 + lane);                    // (64 + lane < 128 <= n)
     const float b = row2 ? q.at(f, 128 + lane) : 0.f;
     q.at(f, lane) = a;
     if (row2) q.at(f, 64 + lane) = b;
   }
 }
-template <int CAP>
-#if RT_SPILL_VARIANT == 1
-__device__ __noinline__
-#else
-__device__ __forceinline__
-#endif
-void queue_take_back(float* qf, const float* src, int at) {
+template <int CAP, int FIELDS>
+__device__ __forceinline__ void queue_take_back(float* qf, const float* src, int at) {
   Queue<CAP> q{qf};
-#if RT_SPILL_VARIANT == 3
-#pragma nounroll
-#else
 #pragma unroll
-#endif
-  for (int k = 0; k < kSpillFields; ++k) q.at(spill_field(k), at) = src[k * 64];
+  for (int f = 0; f < FIELDS; ++f) q.at(f, at) = src[f * 64];
 }
-#if RT_SPILL_VARIANT == 2
-#define RT_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#else
-#define RT_UNLIKELY(x) (x)
-#endif
 
 // OUT: how finished pixels leave — 0: one by one (float / multi-sample / refraction paths), 1: whole tiles from
 // RGBX staging in per-wave tile slots, 2: the same with all samples of a pixel summed in the slot (MULTI), 3: MULTI
@@ -2121,13 +2115,18 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
   constexpr int kThreads = GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock;
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
+  constexpr bool SUMS = MULTI || (REFR && SLOTS);     // a slot holds three sums per pixel (else one RGBX word)
   constexpr int kRing = ring_of(OUT);
   static_assert(GRID == 0 || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
-  static_assert(!SLOTS || !REFR, "refractive scenes sum tree nodes into `accum`: no tile slots");
+  static_assert(!REFR || OUT <= 2, "refractive scenes: scattered sums (0), tile slots (1), all samples in one launch (2)");
   constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
   constexpr int kWaveLdsBytes = wave_lds_bytes(REFR, OUT);
   constexpr int kFields = queue_fields(REFR, OUT);
-  constexpr int kSlots = tile_slots(OUT);
+  constexpr int kSlots = tile_slots(OUT, REFR);
+  // what a slot still waits for, one count per slot in a scalar register pair: hit pixels of the tile (at most 64: a byte),
+  // or — REFR — records of its pixels' trees that are alive in the queue or the spill stack (at most kCap + 32 x 64: 16 bits)
+  constexpr int kCntBits = REFR ? 16 : 8;
+  static_assert(kSlots * kCntBits <= 64, "the slots' counts share one scalar register pair");
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2154,12 +2153,14 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
   // of hit pixels each still waits for in one byte of a scalar register pair (a tile has at most 64)
   uint32_t* slot_stage = reinterpret_cast<uint32_t*>(mine + kFields * kCap * 4 + kRing * kVisTile * 2);   // [kSlots][64] RGBX
   float* slot_sum = reinterpret_cast<float*>(slot_stage);                                                   // MULTI: [kSlots][3][64]
-  uint32_t* slot_hdr = slot_stage + kSlots * 64 * (MULTI ? 3 : 1);                                          // [kSlots][kSlotHdr]
+  uint32_t* slot_fix = slot_stage;                                                                          // REFR: the same as fixed-point sums
+  uint32_t* slot_hdr = slot_stage + kSlots * 64 * (SUMS ? 3 : 1);                                           // [kSlots][kSlotHdr]
   int16_t* slot_next = reinterpret_cast<int16_t*>(slot_hdr + kSlots * kSlotHdr);                            // MULTI: [kSlots][kVisTile]
   uint32_t slot_free = (1u << kSlots) - 1u;                                                                 // wave-uniform
-  unsigned long long slot_left = 0ull;                                                                      // byte k: slot k
+  unsigned long long slot_left = 0ull;                                                                      // field k (kCntBits bits): slot k
   uint32_t slot_ready = 0u;       // MULTI: slots whose current sample is finished and that have another to take in
-  constexpr int kFPixel = REFR ? 9 : 12, kFMeta = REFR ? 10 : SLOTS ? 12 : 13, kFKey = REFR ? 11 : SLOTS ? 13 : 14;   // field numbers
+  constexpr int kFPixel = REFR ? 9 : 12;                                        // field numbers (the pixel: without slots only)
+  constexpr int kFMeta = REFR ? (SLOTS ? 9 : 10) : SLOTS ? 12 : 13, kFKey = kFMeta + 1;
   __syncthreads();   // the only workgroup-wide synchronisation
 
   const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kThreads / 64) + wave);
@@ -2208,20 +2209,41 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
   int sp_blocks = 0;
   auto sp_block = [&](int b) {   // (derived from the kernel arguments where it is needed: the main loop is short of scalar registers)
     const RenderParams& p = params_here();
-    return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane_here();
+    return p.spill + (size_t(gwave) * size_t(p.spill_blocks) + size_t(b)) * size_t(kSpillFields * 64) + lane_here();   // (room for 12 fields)
   };
 
   // ---- a tile's hit pixels (one sample of them) become level-0 records on the queue.  The tile's frame is
   // wave-uniform: its camera and seed come by scalar load; every hit pixel rebuilds its primary ray and hit
   // point exactly as the visibility pass measured them, with all lanes of the tile at work.
   auto take_in = [&](int idx, unsigned long long mask, uint32_t m0, uint32_t m1, int sample, int k) {
-    const int lane = lane_here();
+    int lane = lane_here();
+    if constexpr (REFR && SLOTS) {
+      // Older records first: what is left in the queue (fewer than 64 records, of tiles taken in earlier) moves up above
+      // the new tile's hits, which go to the bottom.  Passes take from the top, so the trees of a tile are finished
+      // before those of the next one are begun, a tile's slot comes free as early as it can, and few slots suffice
+      // (new hits on top would starve the records below them for as long as tiles keep coming).  One lane per record.
+      const int m = __popcll(mask);
+      if (n_bounce > 0 && m > 0) {
+        float rec[kFields];
+        if (lane < n_bounce) {
+#pragma unroll
+          for (int f = 0; f < kFields; ++f) rec[f] = q.at(f, lane);
+        }
+        wave_lds_fence();
+        if (lane < n_bounce) {
+#pragma unroll
+          for (int f = 0; f < kFields; ++f) q.at(f, m + lane) = rec[f];
+        }
+        wave_lds_fence();
+        lane = lane_here();
+      }
+    }
     const RenderParams& p = params_here();
     const int col = int((m0 & 0xFFFFu) * 8u) + (lane & 7), row = int((m0 >> 16) * 8u) + (lane >> 3);
     const int frame = int(m1);
     const FrameRec fr = as_const(p.frames)[frame];
     const int slotpix = k * 64 + lane;
-    if constexpr (SLOTS) slot_left |= (unsigned long long)__popcll(mask) << (8 * k);      // (the byte is 0 now)
+    if constexpr (SLOTS) slot_left |= (unsigned long long)__popcll(mask) << (kCntBits * k);      // (the field is 0 now)
     if (idx >= 0) {
       const rt_camera& cam = fr.cam;
       const int y = p.tile_stride == 1 ? p.y0 + p.tile_first * p.tile_rows + row : row_of(p, row);
@@ -2242,7 +2264,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
         const float t = sphere_t_exact(sg[idx], cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, inv_a, dl);
         px = fmaf(dx, t, cam.origin[0]); py = fmaf(dy, t, cam.origin[1]); pz = fmaf(dz, t, cam.origin[2]);  // :165
       }
-      const int e = n_bounce + lanes_below(mask);
+      const int e = ((REFR && SLOTS) ? 0 : n_bounce) + lanes_below(mask);
       q.at(0, e) = px; q.at(1, e) = py; q.at(2, e) = pz;
       q.at(3, e) = dx; q.at(4, e) = dy; q.at(5, e) = dz;
       q.at(6, e) = 1.f; q.at(7, e) = 1.f; q.at(8, e) = 1.f;          // T = 1
@@ -2269,13 +2291,54 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
           (__attribute__((address_space(3))) void*)(slot_next + k * kVisTile), 4, 0, 0);
   };
 
+  // Slots whose count has reached zero: the tile leaves whole (render :318, :325 -> store_tile8), or — MULTI — its next
+  // sample comes in at the top of the main loop.
+  auto flush_slots = [&](uint32_t complete) {
+    const int fl = lane_here();
+    const RenderParams& p = params_here();
+    // (the lane's share of a tile store — row, dword, source lanes — is worked out here, from a lane number
+    // the compiler cannot trace: hoisted out of the main loop it would sit in six registers across lighting(),
+    // which has none to spare, and go to scratch and back every pass)
+    do {
+      const int k = __ffs(int(complete)) - 1;
+      complete &= complete - 1u;
+      uint32_t rgbx;
+      if constexpr (MULTI) {
+        // a sample of the tile is finished: the next one comes in (top of the loop), or, after the last,
+        // the mean over samples is quantised (render_pixel :297, render :318, :325)
+        if ((__builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 2]) | __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 3])) != 0u) {
+          slot_ready |= 1u << k;
+          continue;
+        }
+      }
+      if constexpr (REFR) {          // fixed-point sums over the nodes of every sample's tree
+        const uint32_t* sum = slot_fix + k * 192 + fl;
+        const float unit = p.inv_samples * (1.0f / kSumScale);
+        rgbx = pack_rgbx(float(sum[0]) * unit, float(sum[64]) * unit, float(sum[128]) * unit);
+      } else if constexpr (MULTI) {
+        const float* sum = slot_sum + k * 192 + fl;
+        rgbx = pack_rgbx(sum[0] * p.inv_samples, sum[64] * p.inv_samples, sum[128] * p.inv_samples);
+      } else {
+        rgbx = slot_stage[k * 64 + fl];
+      }
+      slot_free |= 1u << k;
+      const uint32_t m0 = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k]);
+      const uint32_t frame = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 1]);
+      const int col0 = int((m0 & 0xFFFFu) * 8u), row0 = int((m0 >> 16) * 8u);
+      uint8_t* out = p.out_rgb + (long long)frame * p.frame_stride_px * 3;
+      const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+      store_tile8(out, p.nx, row0, col0, min(8, p.n_rows - row0), min(8, p.nx - col0), fl, rgbx, dwords);
+    } while (complete != 0u);
+    wave_lds_fence();   // the slots' words are read before an intake reuses them
+  };
+
   for (;;) {
     if constexpr (REFR) {
       // fewer than a pass's worth of records in LDS and a block set aside: it comes back, on top of the queue
       // (positions below 128 <= H, like a tile's fresh hits), before any new tile is taken in
-      if (RT_UNLIKELY(n_bounce < 64 && sp_blocks > 0)) {
+      if ((n_bounce < 64 && sp_blocks > 0)) {
         --sp_blocks;
-        queue_take_back<kCap>(q.f, sp_block(sp_blocks), n_bounce + lane_here());
+        queue_take_back<kCap, kFields>(q.f, sp_block(sp_blocks), n_bounce + lane_here());
         n_bounce += 64;
         wave_lds_fence();
         continue;
@@ -2417,7 +2480,8 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
               if (todo != 0ull) request_next(k, m0, m1, __ffsll((long long)todo) - 1);
               if (sample < 0) slot_ready |= 1u << k;           // nothing in sample 0: the next one can come in at once
             } else {
-              slot_stage[k * 64 + lane] = 0u;
+              if constexpr (SUMS) { slot_fix[k * 192 + lane] = 0u; slot_fix[k * 192 + 64 + lane] = 0u; slot_fix[k * 192 + 128 + lane] = 0u; }
+              else slot_stage[k * 64 + lane] = 0u;
               if (lane == 0) { slot_hdr[kSlotHdr * k] = m0; slot_hdr[kSlotHdr * k + 1] = m1; }
             }
           }
@@ -2480,8 +2544,8 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
           };
           const int want = nb;
           nb = run(n_bounce);
-          if (RT_UNLIKELY(nb + 8 <= want && n_bounce >= 128 && sp_blocks < p.spill_blocks)) {   // cut short for want of room
-            queue_set_aside<kCap>(q.f, sp_block(sp_blocks), lane, n_bounce);
+          if ((nb + 8 <= want && n_bounce >= 128 && sp_blocks < p.spill_blocks)) {   // cut short for want of room
+            queue_set_aside<kCap, kFields>(q.f, sp_block(sp_blocks), lane, n_bounce);
             ++sp_blocks;
             n_bounce -= 64;                                          // (still >= 64: the top `want` = 64 records are the same ones)
             wave_lds_fence();
@@ -2565,14 +2629,34 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             light_colour(p.L, lw, m.x, m.y, m.z, spec, lr, lg, lb);
           }
           const RenderParams& p = params_here();
-          const int level = meta_level(meta), rframe = meta_frame(meta);
+          const int level = meta_level(meta);
+          [[maybe_unused]] const int rframe = SLOTS ? 0 : meta_frame(meta);
+          // the bits of the meta word that the children keep: the pixel's slot and position, or its frame
+          const uint32_t meta_home = SLOTS ? (meta & 0x0000FF80u) : (uint32_t(rframe) << 7);
           s2 = RT_NOW();
           const float refl = m.w, refr = rf.x;
           const float own = (1.0f - refl) * (1.0f - refr);                   // :249, :254 (1 - 0 = 1 exactly)
-          float* a = p.accum + ((long long)rframe * p.accum_stride_px + wpix) * 3;
-          unsafeAtomicAdd(a + 0, tr * (m.x * own) * lr);
-          unsafeAtomicAdd(a + 1, tg * (m.y * own) * lg);
-          unsafeAtomicAdd(a + 2, tb * (m.z * own) * lb);
+          if constexpr (SLOTS) {
+            // the node's share joins its pixel's sums in the tile's slot: fixed point, saturating (a wrapped add is
+            // followed by a store of the largest value; shares are never negative — the host takes this path only for
+            // scenes whose colours, intensities and coefficients make it so —, so a sum that has once saturated stays
+            // there and the pixel clamps to white, as the reference's would).  Two records of one pixel in one pass
+            // (the two children of a node, usually) add to one address: the LDS serialises them, and integer
+            // addition does not care in which order.
+            uint32_t* sum = slot_fix + (meta_slotpix(meta) >> 6) * 192 + (meta_slotpix(meta) & 63);
+            const uint32_t qr = uint32_t(fmaf(tr * (m.x * own) * lr, kSumScale, 0.5f));
+            const uint32_t qg = uint32_t(fmaf(tg * (m.y * own) * lg, kSumScale, 0.5f));
+            const uint32_t qb = uint32_t(fmaf(tb * (m.z * own) * lb, kSumScale, 0.5f));
+            const uint32_t wr = atomicAdd(sum, qr), wg = atomicAdd(sum + 64, qg), wb = atomicAdd(sum + 128, qb);
+            if (wr + qr < wr) atomicMax(sum, 0xFFFFFFFFu);
+            if (wg + qg < wg) atomicMax(sum + 64, 0xFFFFFFFFu);
+            if (wb + qb < wb) atomicMax(sum + 128, 0xFFFFFFFFu);
+          } else {
+            float* a = p.accum + ((long long)rframe * p.accum_stride_px + wpix) * 3;
+            unsafeAtomicAdd(a + 0, tr * (m.x * own) * lr);
+            unsafeAtomicAdd(a + 1, tg * (m.y * own) * lg);
+            unsafeAtomicAdd(a + 2, tb * (m.z * own) * lb);
+          }
           const bool deeper = level < p.max_depth;                           // :233 `depth > D` -> black
           if (refl > 0.0f && deeper) {                                       // :245-248
             const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));
@@ -2587,7 +2671,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
               hit_point<CUBES>(sg, p.n_spheres, idx2, face, sx, sy, sz, rdx, rdy, rdz, t, rpx, rpy, rpz);
               const float k = refl * (1.0f - refr);
               rtr = tr * k * lr; rtg = tg * k * lg; rtb = tb * k * lb;
-              meta_r = pack_meta(level + 1, rframe, idx2);
+              meta_r = meta_home | uint32_t(level + 1) | (uint32_t(idx2) << 20);
             }
           }
           if (refr > 0.0f && deeper) {                                       // :252-253 -> compute_refraction
@@ -2616,7 +2700,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
                 push_f = true;
                 hit_point<CUBES>(sg, p.n_spheres, idx2, face, ox, oy, oz, fdx, fdy, fdz, t, fpx, fpy, fpz);
                 ftr = tr * refr * lr; ftg = tg * refr * lg; ftb = tb * refr * lb;
-                meta_f = pack_meta(level + 1, rframe, idx2);
+                meta_f = meta_home | uint32_t(level + 1) | (uint32_t(idx2) << 20);
               }
             }
           }
@@ -2630,7 +2714,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
           q.at(0, slot) = rpx; q.at(1, slot) = rpy; q.at(2, slot) = rpz;
           q.at(3, slot) = rdx; q.at(4, slot) = rdy; q.at(5, slot) = rdz;
           q.at(6, slot) = rtr; q.at(7, slot) = rtg; q.at(8, slot) = rtb;
-          q.at(kFPixel, slot) = __uint_as_float(wpix);
+          if constexpr (!SLOTS) q.at(kFPixel, slot) = __uint_as_float(wpix);
           q.at(kFMeta, slot) = __uint_as_float(meta_r);
           q.at(kFKey, slot) = __uint_as_float(pixel_key);
         }
@@ -2639,12 +2723,28 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
           q.at(0, slot) = fpx; q.at(1, slot) = fpy; q.at(2, slot) = fpz;
           q.at(3, slot) = fdx; q.at(4, slot) = fdy; q.at(5, slot) = fdz;
           q.at(6, slot) = ftr; q.at(7, slot) = ftg; q.at(8, slot) = ftb;
-          q.at(kFPixel, slot) = __uint_as_float(wpix);
+          if constexpr (!SLOTS) q.at(kFPixel, slot) = __uint_as_float(wpix);
           q.at(kFMeta, slot) = __uint_as_float(meta_f);
           q.at(kFKey, slot) = __uint_as_float(pixel_key);
         }
         n_bounce = min(kCap, base + __popcll(mask_r) + __popcll(mask_f));
         wave_lds_fence();
+        if constexpr (SLOTS) {
+          // records of each slot's trees: this pass's have gone, their children have come; a slot whose count reaches
+          // zero has every node of every pixel in its sums (one turn per slot that had records in the pass)
+          uint32_t complete = 0u;
+          const int fslot = meta_slotpix(meta) >> 6;
+          unsigned long long todo = __ballot(have);
+          while (todo != 0ull) {
+            const int k = __builtin_amdgcn_readlane(fslot, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(have && fslot == k);
+            todo &= ~same;
+            const long long delta = (long long)(__popcll(mask_r & same) + __popcll(mask_f & same)) - (long long)__popcll(same);
+            slot_left += (unsigned long long)(delta << (kCntBits * k));      // (the field stays within 0 .. 65535: no borrow)
+            if (((slot_left >> (kCntBits * k)) & ((1ull << kCntBits) - 1ull)) == 0ull) complete |= 1u << k;
+          }
+          if (complete != 0u) flush_slots(complete);
+        }
         const unsigned long long s3 = RT_NOW();
         st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
         continue;
@@ -2723,43 +2823,12 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             const int k = __builtin_amdgcn_readlane(fslot, __ffsll((long long)fin) - 1);
             const unsigned long long same = __ballot(have && !again && fslot == k);
             fin &= ~same;
-            slot_left -= (unsigned long long)__popcll(same) << (8 * k);
-            if (((slot_left >> (8 * k)) & 0xFFull) == 0ull) complete |= 1u << k;
+            slot_left -= (unsigned long long)__popcll(same) << (kCntBits * k);
+            if (((slot_left >> (kCntBits * k)) & ((1ull << kCntBits) - 1ull)) == 0ull) complete |= 1u << k;
           }
         }
         // tiles whose last hit pixel finished in this pass leave as whole tiles (render :318, :325)
-        const int fl = lane_here();
-        if (complete != 0u) {
-          const RenderParams& p = params_here();
-          // (the lane's share of a tile store — row, dword, source lanes — is worked out here, from a lane number
-          // the compiler cannot trace: hoisted out of the main loop it would sit in six registers across lighting(),
-          // which has none to spare, and go to scratch and back every pass)
-          do {
-            const int k = __ffs(int(complete)) - 1;
-            complete &= complete - 1u;
-            uint32_t rgbx;
-            if constexpr (MULTI) {
-              // a sample of the tile is finished: the next one comes in (top of the loop), or, after the last,
-              // the mean over samples is quantised (render_pixel :297, render :318, :325)
-              if ((__builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 2]) | __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 3])) != 0u) {
-                slot_ready |= 1u << k;
-                continue;
-              }
-              const float* sum = slot_sum + k * 192 + fl;
-              rgbx = pack_rgbx(sum[0] * p.inv_samples, sum[64] * p.inv_samples, sum[128] * p.inv_samples);
-            } else {
-              rgbx = slot_stage[k * 64 + fl];
-            }
-            slot_free |= 1u << k;
-            const uint32_t m0 = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k]);
-            const uint32_t frame = __builtin_amdgcn_readfirstlane(slot_hdr[kSlotHdr * k + 1]);
-            const int col0 = int((m0 & 0xFFFFu) * 8u), row0 = int((m0 >> 16) * 8u);
-            uint8_t* out = p.out_rgb + (long long)frame * p.frame_stride_px * 3;
-            const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
-            store_tile8(out, p.nx, row0, col0, min(8, p.n_rows - row0), min(8, p.nx - col0), fl, rgbx, dwords);
-          } while (complete != 0u);
-          wave_lds_fence();   // the slots' words are read before an intake reuses them
-        }
+        if (complete != 0u) flush_slots(complete);
       }
       const unsigned long long s3 = RT_NOW();
       st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
@@ -3035,8 +3104,9 @@ thread_local std::string g_last_error;
 // buffers of the other entry points.
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 namespace {
-constexpr int kMaxDevices = 64;
-unsigned char* g_scratch_ptr[kMaxDevices];   // per device: address of ITS copy of `scratch` (rt_create)
+constexpr int kMaxDevices = 64;              // (devices with a higher id get no scratch array: rt_render_noalloc refuses there)
+unsigned char* g_scratch_ptr[kMaxDevices];   // per device: address of ITS copy of `scratch` (rt_create, under g_scratch_mutex)
+std::mutex g_scratch_mutex;
 }
 
 // REFR path: every pixel of the window from its sum over samples and tree nodes in `accum`
@@ -3108,6 +3178,7 @@ __global__ __launch_bounds__(128) void rt_resolve_tiles_kernel(const RenderParam
 // ------------------------------------------------------------------------------------------
 struct rt_ctx {
   int device = -1;
+  unsigned char* scratch = nullptr;   // this device's copy of the `scratch` array (rt_render_noalloc), from rt_create
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   float4* d_geom = nullptr;
@@ -3116,6 +3187,11 @@ struct rt_ctx {
   float2* d_refr = nullptr;      // refraction, refractive_index per object (rt_set_refraction, rt_set_cubes)
   bool has_refr = false;         // some sphere has refraction > 0: the REFR kernels run
   bool has_refr_cubes = false;   // some cube has
+  // no colour, intensity or coefficient of the scene is negative and reflection / refraction lie in [0, 1], so no node of a
+  // pixel's tree contributes a negative share: the refractive kernels may sum in saturating fixed point (spheres + lights /
+  // their refraction values / the cubes)
+  bool nonneg_scene = true, nonneg_refr = true, nonneg_cubes = true;
+  bool sums_never_negative() const { return nonneg_scene && nonneg_refr && nonneg_cubes; }
   uint32_t* d_grid_start = nullptr;   // sphere grid of many-sphere scenes (build_sphere_grid)
   uint16_t* d_grid_items = nullptr;
   uint16_t* d_grid_big = nullptr;
@@ -3483,47 +3559,39 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false
   if (rng_mode == RT_RNG_KEYED) return cubes ? rt_visibility_kernel<RT_RNG_KEYED, true> : rt_visibility_kernel<RT_RNG_KEYED, false>;
   return cubes ? rt_visibility_kernel<RT_RNG_CONSTANT, true> : rt_visibility_kernel<RT_RNG_CONSTANT, false>;
 }
-template <int OUT>
-RenderKernel pick_slot_kernel(int rng_mode, bool cubes, int grid) {
-  if constexpr (OUT < 3) {   // (a scene that has a grid or lists never fits OUT = 3's four workgroups)
-    if constexpr (OUT == 1) {   // (OUT = 2 is compiled for three waves per SIMD as it is)
-      if (grid == 3 && !cubes)
-        return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 3, OUT>
-                                        : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 3, OUT>;
-      if (grid == 2 && !cubes)
-        return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 2, OUT>
-                                        : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 2, OUT>;
-    }
-    if (grid && !cubes)
-      return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 1, OUT>
-                                      : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 1, OUT>;
-  }
-  if (rng_mode == RT_RNG_KEYED)
-    return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true, 0, OUT> : rt_stream_kernel<RT_RNG_KEYED, false, false, 0, OUT>;
-  return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true, 0, OUT> : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 0, OUT>;
-}
-// out: 0 = finished pixels are stored one by one, 1 = tile by tile (the default for 8-bit frames), 2 = tile by
-// tile with all samples of a pixel in one launch, 3 = the same with fewer slots (small scenes: four workgroups per CU)
+// The stream kernel's variants, ONE table: pick_stream_kernel() looks a variant up in it and rt_create() walks it to
+// allow every variant its dynamic LDS — a variant that is not listed here cannot be launched, and one that is listed
+// cannot be forgotten by either.
+//   refr / cubes: the scene has refractive materials / boxes       grid: 0 = bit tables, 1 = lists (256 spheres and
+//   more), 2 / 3 = lists in workgroups of eight / sixteen waves    out: 0 = pixels one by one (float output, running
+//   sums), 1 = tile slots, 2 = all samples of a pixel in one launch, 3 / 4 = the same with three slots (four-wave /
+//   eight-wave workgroups)
+struct StreamVariant {
+  bool refr, cubes;
+  int grid, out;
+  RenderKernel keyed, constant;
+};
+#define RT_STREAM_VARIANT(R, C, G, O) \
+  {R, C, G, O, rt_stream_kernel<RT_RNG_KEYED, R, C, G, O>, rt_stream_kernel<RT_RNG_CONSTANT, R, C, G, O>}
+const StreamVariant kStreamVariants[] = {
+    // opaque scenes
+    RT_STREAM_VARIANT(false, false, 0, 0), RT_STREAM_VARIANT(false, true, 0, 0),
+    RT_STREAM_VARIANT(false, false, 1, 0), RT_STREAM_VARIANT(false, false, 2, 0), RT_STREAM_VARIANT(false, false, 3, 0),
+    RT_STREAM_VARIANT(false, false, 0, 1), RT_STREAM_VARIANT(false, true, 0, 1),
+    RT_STREAM_VARIANT(false, false, 1, 1), RT_STREAM_VARIANT(false, false, 2, 1), RT_STREAM_VARIANT(false, false, 3, 1),
+    RT_STREAM_VARIANT(false, false, 0, 2), RT_STREAM_VARIANT(false, true, 0, 2), RT_STREAM_VARIANT(false, false, 1, 2),
+    RT_STREAM_VARIANT(false, false, 0, 3), RT_STREAM_VARIANT(false, true, 0, 3),
+    RT_STREAM_VARIANT(false, false, 0, 4), RT_STREAM_VARIANT(false, true, 0, 4),
+    // refractive scenes: float sums in device memory (0), fixed-point sums in tile slots (1)
+    RT_STREAM_VARIANT(true, false, 0, 0), RT_STREAM_VARIANT(true, true, 0, 0),
+    RT_STREAM_VARIANT(true, false, 0, 1), RT_STREAM_VARIANT(true, true, 0, 1),
+};
+#undef RT_STREAM_VARIANT
 RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, int grid = 0, int out = 0) {
-  if (out == 1 && !refr) return pick_slot_kernel<1>(rng_mode, cubes, grid);
-  if (out == 2 && !refr) return pick_slot_kernel<2>(rng_mode, cubes, grid);
-  if (out == 3 && !refr) return pick_slot_kernel<3>(rng_mode, cubes, 0);
-  if (out == 4 && !refr) return pick_slot_kernel<4>(rng_mode, cubes, 0);
-  if (grid == 3 && !refr && !cubes)
-    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 3>
-                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 3>;
-  if (grid == 2 && !refr && !cubes)
-    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 2>
-                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 2>;
-  if (grid && !refr && !cubes)
-    return rng_mode == RT_RNG_KEYED ? rt_stream_kernel<RT_RNG_KEYED, false, false, 1>
-                                    : rt_stream_kernel<RT_RNG_CONSTANT, false, false, 1>;
-  if (rng_mode == RT_RNG_KEYED) {
-    if (refr) return cubes ? rt_stream_kernel<RT_RNG_KEYED, true, true> : rt_stream_kernel<RT_RNG_KEYED, true, false>;
-    return cubes ? rt_stream_kernel<RT_RNG_KEYED, false, true> : rt_stream_kernel<RT_RNG_KEYED, false, false>;
-  }
-  if (refr) return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, true, true> : rt_stream_kernel<RT_RNG_CONSTANT, true, false>;
-  return cubes ? rt_stream_kernel<RT_RNG_CONSTANT, false, true> : rt_stream_kernel<RT_RNG_CONSTANT, false, false>;
+  for (const StreamVariant& v : kStreamVariants)
+    if (v.refr == refr && v.cubes == cubes && v.grid == grid && v.out == out)
+      return rng_mode == RT_RNG_KEYED ? v.keyed : v.constant;
+  return nullptr;     // (launch() refuses: a combination the host logic must not ask for)
 }
 
 // Validates, then launches ceil(n_frames / RT_FRAMES_PER_LAUNCH) x samples kernel pairs on ctx->stream.
@@ -3561,10 +3629,15 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // (the kernels count tiles of a batch in 32-bit integers)
   const long long frame_tiles = (long long)(((w.nx + 7) / 8) | 1) * ((w.n_rows + 7) / 8);   // tile ids per frame (odd pitch)
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
-  // refractive scenes add every tree node into a float slab per frame (12 B per pixel): a launch holds as many
-  // frames as fit kRefrSumBytes of them (1024 at 1080p, 321 at 4K)
-  const int frames_cap = refr ? int(std::max<long long>(1, std::min<long long>(kMaxBatch, kRefrSumBytes / (12 * std::max<long long>(win_px, 1)))))
-                              : kMaxBatch;
+  // Refractive scenes, 8-bit frames at one sample per pixel: the stream kernel sums a pixel's tree in its tile's slot
+  // (fixed point: needs shares that are never negative, which rt_upload_scene / rt_set_refraction / rt_set_cubes have
+  // checked).  Otherwise (float output, several samples, RT_OPT_TILE_FLUSH off, a scene with negative colours) every node
+  // adds into a float slab per frame (12 B per pixel) with float atomics, and a launch holds as many frames as fit
+  // kRefrSumBytes of slabs (1024 at 1080p, 321 at 4K).
+  const bool refr_slots = refr && ctx->kernel == RT_KERNEL_STREAM && ctx->tile_flush && ctx->sums_never_negative() && out_rgb &&
+                          !out_f32 && samples == 1;
+  const int frames_cap = (refr && !refr_slots) ? int(std::max<long long>(1, std::min<long long>(kMaxBatch, kRefrSumBytes / (12 * std::max<long long>(win_px, 1)))))
+                                               : kMaxBatch;
   const int max_batch = int(std::max<long long>(1, std::min<long long>(frames_cap, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
   const int batch = std::min(n_frames, max_batch);
   const bool cubes = ctx->n_cubes > 0;
@@ -3576,7 +3649,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
                                 "that are allocated on demand", samples, int(refr));
   const bool stream_kernel_early = ctx->kernel == RT_KERNEL_STREAM;
   const bool multi_early = stream_kernel_early && ctx->tile_flush && !refr && out_rgb && !out_f32 && samples >= 2 && samples <= 64;
-  if ((samples > 1 && !multi_early) || refr) {  // running sums over samples (and tree nodes), one slab per frame of a batch
+  if ((samples > 1 && !multi_early) || (refr && !refr_slots)) {  // running sums over samples (and tree nodes), one slab per frame of a batch
     const size_t need = size_t(win_px) * 3 * size_t(batch);
     if (need > ctx->accum_floats) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -3605,11 +3678,12 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   // 8-bit frames at one sample per pixel: the stream kernel stages finished pixels per tile and stores whole tiles
   // ... and with 2..64 samples per pixel all of them are traced in ONE launch pair and summed in the slots
-  int slots = (stream_kernel && ctx->tile_flush && !refr && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
+  int slots = refr ? (refr_slots ? 1 : 0)
+                   : (stream_kernel && ctx->tile_flush && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
   // ... unless the slots' LDS would cost a resident workgroup per CU (many-sphere scenes, whose sphere list takes
   // 16 B per sphere of every workgroup's LDS): config 4 measured 88 Grays/s on three workgroups per CU with
   // scattered stores against 65 on two with tile stores
-  if (slots == 1 && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 1)) <
+  if (slots == 1 && !refr && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 1)) <
                         workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 0)))
     slots = 0;
   // all samples in one launch: the variant with three slots per wave where that buys a fourth workgroup per CU (scenes of
@@ -3679,8 +3753,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   for (int k = 0; k < 3; ++k) {
     p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];
   }
-  p.defer_output = refr ? 1 : 0;
-  p.defer_sparse = (refr && stream_kernel && samples == 1 && out_rgb && !out_f32) ? 1 : 0;
+  p.defer_output = (refr && !refr_slots) ? 1 : 0;
+  p.defer_sparse = (refr && !refr_slots && stream_kernel && samples == 1 && out_rgb && !out_f32) ? 1 : 0;
   p.tile_flush = slots ? 1 : 0;
   p.accum = ctx->d_accum;
   p.spill = ctx->d_spill; p.spill_blocks = spill_blocks;
@@ -3785,7 +3859,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         RT_HIP(ctx, hipGetLastError());
       }
     }
-    if (refr && !p.defer_sparse)   // every node of every sample adds into the pixel sums (defer_sparse: the visibility pass
+    if (p.defer_output && !p.defer_sparse)   // every node of every sample adds into the pixel sums (defer_sparse: the visibility pass
       RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));   // clears those of occupied tiles)
     if (multi)   // which samples of a tile hit anything: collected by the visibility launches below
       RT_HIP(ctx, hipMemsetAsync(ctx->d_present, 0, (size_t(frame_tiles) * size_t(nf) + 8) * sizeof(unsigned long long), ctx->stream));
@@ -3809,9 +3883,12 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         if (!multi || s == 0) RT_HIP(ctx, hipMemsetAsync(d_chunk, 0, chunk_need, ctx->stream));
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi, ctx->n_spheres > 64), vgrid, dim3(RT_VIS_BLOCK), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
-        if (!multi || s + 1 == samples)
-          hipLaunchKernelGGL(pick_stream_kernel(rng_mode, refr, cubes, list_kernel, slots), sgrid, dim3(threads), lds, ctx->stream, p);
-        if (refr && s + 1 == samples) {   // (never MULTI)
+        if (!multi || s + 1 == samples) {
+          const RenderKernel shade = pick_stream_kernel(rng_mode, refr, cubes, list_kernel, slots);
+          if (!shade) return fail(ctx, RT_ESTATE, "no stream kernel variant for refr %d cubes %d lists %d output %d", int(refr), int(cubes), list_kernel, slots);
+          hipLaunchKernelGGL(shade, sgrid, dim3(threads), lds, ctx->stream, p);
+        }
+        if (p.defer_output && s + 1 == samples) {   // (never MULTI)
           if (p.defer_sparse)
             hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 8 * kVisRows - 1) / (8 * kVisRows)), unsigned((w.nx + 16 * kVisTiles - 1) / (16 * kVisTiles)), unsigned(nf)),
                                dim3(128), 0, ctx->stream, p);
@@ -3869,12 +3946,17 @@ int rt_create(int device_id, rt_ctx** out) {
     return rc;
   };
   if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
-  if (device_id < kMaxDevices && !g_scratch_ptr[device_id]) {
-    // this device's copy of the scratch array of rt_render_noalloc (every GPU has its own, at its own address)
-    unsigned char* ptr = nullptr;
-    if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch))) != hipSuccess)
-      return bail(e, "hipGetSymbolAddress(scratch)");
-    g_scratch_ptr[device_id] = ptr;
+  if (device_id < kMaxDevices) {
+    // this device's copy of the scratch array of rt_render_noalloc (every GPU has its own, at its own address); contexts
+    // may be created from several threads
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device_id]) {
+      unsigned char* ptr = nullptr;
+      if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch))) != hipSuccess)
+        return bail(e, "hipGetSymbolAddress(scratch)");
+      g_scratch_ptr[device_id] = ptr;
+    }
+    ctx->scratch = g_scratch_ptr[device_id];
   }
   if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
@@ -3901,26 +3983,12 @@ int rt_create(int device_id, rt_ctx** out) {
     return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords)) != hipSuccess)
     return bail(e, "hipMemset");
-  const size_t big = stream_lds(RT_MAX_SPHERES), bigr = stream_lds(RT_MAX_SPHERES, true);
-  for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-    for (int r = 0; r < 2; ++r)
-      for (int c = 0; c < 2; ++c)
-        if ((e = allow_big_lds(pick_stream_kernel(mode, r != 0, c != 0), r ? bigr : big)) != hipSuccess)
-          return bail(e, "hipFuncSetAttribute");
-  for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-    for (int g = 1; g <= 3; ++g)
-      if ((e = allow_big_lds(pick_stream_kernel(mode, false, false, g), g >= 2 ? size_t(160 * 1024) : big)) != hipSuccess ||
-          (e = allow_big_lds(pick_stream_kernel(mode, false, false, g, 1), g >= 2 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, 1))) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute");
-  for (int out = 1; out <= 4; ++out) {
-    const size_t bigs = out == 4 ? size_t(160 * 1024) : stream_lds(RT_MAX_SPHERES, false, out);
-    for (int mode : {RT_RNG_CONSTANT, RT_RNG_KEYED})
-      for (int v = 0; v < (out >= 3 ? 2 : 3); ++v)   // plain, cubes, grid
-        if ((e = allow_big_lds(pick_stream_kernel(mode, false, v == 1, v == 2 ? 1 : 0, out), bigs)) != hipSuccess)
-          return bail(e, "hipFuncSetAttribute");
-  }
-  if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, big)) != hipSuccess ||
-      (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, big)) != hipSuccess)
+  // every kernel with dynamic LDS may use all of a CU's 160 KB (the launch says how much it takes)
+  for (const StreamVariant& v : kStreamVariants)
+    if ((e = allow_big_lds(v.keyed, size_t(160 * 1024))) != hipSuccess || (e = allow_big_lds(v.constant, size_t(160 * 1024))) != hipSuccess)
+      return bail(e, "hipFuncSetAttribute");
+  if ((e = allow_big_lds(rt_pixel_kernel<RT_RNG_KEYED>, stream_lds(RT_MAX_SPHERES))) != hipSuccess ||
+      (e = allow_big_lds(rt_pixel_kernel<RT_RNG_CONSTANT>, stream_lds(RT_MAX_SPHERES))) != hipSuccess)
     return bail(e, "hipFuncSetAttribute");
   *out = ctx;
   return RT_OK;
@@ -4023,6 +4091,11 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   RT_HIP(ctx, hipSetDevice(ctx->device));
   // the previous scene may still be in use by launches in flight on the stream
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // From here on the device holds neither the old scene nor the new one: a failure below leaves the context without a
+  // scene (renders return RT_ESTATE) instead of the old sphere count and flags over the new geometry.
+  ctx->n_spheres = -1;
+  ctx->has_refr = false; ctx->n_cubes = 0; ctx->has_refr_cubes = false;
+  ctx->nonneg_refr = true; ctx->nonneg_cubes = true;
   {   // eight never-hit spheres behind the list: nearest_hit reads it in blocks of four, one block ahead
     float pad[8 * 4];
     for (int i = 0; i < 8; ++i) { pad[4 * i] = pad[4 * i + 1] = pad[4 * i + 2] = 0.0f; pad[4 * i + 3] = -INFINITY; }
@@ -4134,10 +4207,16 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     }
   }
   RT_HIP(ctx, hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32)));
+  {   // can a node of a pixel's tree contribute a negative share?  (see rt_ctx::sums_never_negative)
+    bool ok = lights->point_intensity >= 0.f && lights->area_intensity >= 0.f;
+    for (int k = 0; k < 3; ++k) ok = ok && lights->point_color[k] >= 0.f && lights->area_color[k] >= 0.f;
+    for (int i = 0; i < n_spheres && ok; ++i)
+      ok = mat4[4 * i] >= 0.f && mat4[4 * i + 1] >= 0.f && mat4[4 * i + 2] >= 0.f && mat4[4 * i + 3] >= 0.f && mat4[4 * i + 3] <= 1.f &&
+           spec[i] >= 0.f;
+    ctx->nonneg_scene = ok;
+  }
+  // (Material's defaults, raytracer.py:43, until rt_set_refraction says otherwise; spheres only until rt_set_cubes does)
   ctx->n_spheres = n_spheres;
-  ctx->has_refr = false;   // Material's defaults (raytracer.py:43) until rt_set_refraction says otherwise
-  ctx->n_cubes = 0;        // the object list holds spheres only until rt_set_cubes says otherwise
-  ctx->has_refr_cubes = false;
   return RT_OK;
 }
 
@@ -4151,7 +4230,7 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
   if (n_cubes > 0 && (!box6 || !mat4 || !spec)) return fail(ctx, RT_EINVAL, "cube array is NULL");
   std::vector<float4> box(size_t(2 * std::max(n_cubes, 1)));
   std::vector<float2> rf(size_t(std::max(n_cubes, 1)));
-  bool any = false;
+  bool any = false, nonneg = true;
   for (int i = 0; i < n_cubes; ++i) {
     for (int k = 0; k < 6; ++k)
       if (!std::isfinite(box6[6 * i + k])) return fail(ctx, RT_EINVAL, "cube %d has a non-finite corner", i);
@@ -4165,6 +4244,8 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
     box[size_t(2 * i + 1)] = make_float4(box6[6 * i + 3], box6[6 * i + 4], box6[6 * i + 5], 0.0f);
     rf[size_t(i)] = make_float2(f, ri);
     any = any || f > 0.0f;
+    nonneg = nonneg && mat4[4 * i] >= 0.f && mat4[4 * i + 1] >= 0.f && mat4[4 * i + 2] >= 0.f && mat4[4 * i + 3] >= 0.f &&
+             mat4[4 * i + 3] <= 1.f && spec[i] >= 0.f && f >= 0.f && f <= 1.f;
   }
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -4186,6 +4267,7 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
   }
   ctx->n_cubes = n_cubes;
   ctx->has_refr_cubes = any;
+  ctx->nonneg_cubes = nonneg;
   return RT_OK;
 }
 
@@ -4220,7 +4302,7 @@ int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refract
     return fail(ctx, RT_EINVAL, "n_spheres %d does not match the uploaded scene (%d)", n_spheres, ctx->n_spheres);
   if (n_spheres > 0 && (!refraction || !refractive_index)) return fail(ctx, RT_EINVAL, "NULL array");
   std::vector<float2> h(size_t(std::max(n_spheres, 1)));
-  bool any = false;
+  bool any = false, nonneg = true;
   for (int i = 0; i < n_spheres; ++i) {
     if (!std::isfinite(refraction[i]) || !std::isfinite(refractive_index[i]))
       return fail(ctx, RT_EINVAL, "sphere %d: non-finite refraction value", i);
@@ -4228,6 +4310,7 @@ int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refract
       return fail(ctx, RT_EINVAL, "sphere %d: refractive_index must be > 0", i);
     h[size_t(i)] = make_float2(refraction[i], refractive_index[i]);
     any = any || refraction[i] > 0.0f;
+    nonneg = nonneg && refraction[i] >= 0.0f && refraction[i] <= 1.0f;
   }
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -4240,6 +4323,7 @@ int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refract
     RT_HIP(ctx, hipMemcpy(ctx->d_glass_bits, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
   }
   ctx->has_refr = any;
+  ctx->nonneg_refr = nonneg;
   return RT_OK;
 }
 
@@ -4254,7 +4338,7 @@ int rt_render_noalloc(rt_ctx* ctx, const rt_camera* cam, int width, int height, 
                       int rng_mode, uint64_t seed, uint8_t* out_rgb, int32_t* out_hit) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (!out_rgb) return fail(ctx, RT_EINVAL, "out_rgb is NULL");
-  unsigned char* ws = (ctx->device >= 0 && ctx->device < kMaxDevices) ? g_scratch_ptr[ctx->device] : nullptr;
+  unsigned char* ws = ctx->scratch;
   if (!ws) return fail(ctx, RT_ESTATE, "rt_render_noalloc: no scratch array on device %d", ctx->device);
   Window w{0, width, height, height > 0 ? height : 1, 0, 1, 0};
   return launch(ctx, cam, &seed, 1, width, height, w, samples, max_depth, rng_mode, out_rgb, nullptr, out_hit, 0, ws);

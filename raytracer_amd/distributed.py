@@ -7,8 +7,10 @@ t = rank, rank+G, ... of the frame with the same keyed RNG, so the assembled ima
 summation order, i.e. <= 1/255 on a few pixels, run to run as across GPU counts).  The only
 collective on the data path is a fixed-size ``gather`` to rank 0 — G-1 concurrent point-to-point transfers, one
 per xGMI link into GPU 0 — followed by the placement on the root.  The reference has no distributed code; its
-unused ``render_chunk`` tile split (raytracer.py:299-308) is the model.  RCCL itself has not run yet (one GPU
-per development box): the collectives here have met gloo only.
+unused ``render_chunk`` tile split (raytracer.py:299-308) is the model.  Development boxes have one GPU: the RCCL
+path has run there as a group of ONE rank (``force_collectives``: every collective call of the N > 1 path, device
+tensors, the side stream — tests/test_gpu_rccl.py, bench.py with RT_BENCH_FORCE_EXCHANGE=1), several ranks only over
+gloo.
 """
 from __future__ import annotations
 
@@ -89,15 +91,28 @@ class BatchExchange:
                    host waits) and ONE gather moves [max count, entry_bytes] per rank — instead of the slab;
       submit(i+2): ``place_tiles(entries [world, max count, entry_bytes], counts [world] (device), i)`` on the root
                    (Renderer.place_tiles: one pass over the frames, black where no tile lands).
-    Buffers: two slabs and three entry buffers per rank (a batch's entries live until its gather is done)."""
+    Buffers: two slabs and three entry buffers per rank (a batch's entries live until its gather is done).
+
+    With RCCL (device tensors, backend nccl) nothing of the exchange is queued on the render stream: the counts of a
+    batch are copied to pinned host memory on a SIDE stream that waits for the count exchange alone, and the host reads
+    them after an event there — not after the renders it has queued since —; the gather is issued from the side stream
+    (RCCL's stream then waits for that batch's compaction, not for later renders), and the root's placement runs there
+    too, beside its own render (``place_tiles`` is called with the side stream current and must launch on it).  The
+    render stream only waits, three batches later, for the gather that read the entry buffer it is about to overwrite.
+    ``force_collectives``: a group of one rank still goes through every collective (the one-GPU rehearsal of this path).
+    """
 
     def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0, *,
-                 compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196):
+                 compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196,
+                 force_collectives: bool = False):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
+        # device tensors over RCCL: the side-stream pipeline described above
+        self.on_side = self.collectives and torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl"
         self.slabs = [torch.zeros((n_frames, slab_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
         self.sparse = compact is not None
         if self.sparse and (place_tiles is None or not capacity):
@@ -108,6 +123,11 @@ class BatchExchange:
             self.count = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(3)]
             self.capacity = int(capacity)
             self.gathered = [None, None]
+            if self.on_side:
+                self.side = torch.cuda.Stream(device=device)
+                self.counts_all = [torch.zeros(self.world, dtype=torch.int32, device=device) for _ in range(3)]
+                self.counts_host = [torch.zeros(self.world, dtype=torch.int32).pin_memory() for _ in range(3)]
+                self.reusable = [None, None, None]   # event on the side stream: the gather that read entries[b] is done
         else:
             self.gathered = [torch.empty((self.world, n_frames, slab_bytes), dtype=torch.uint8, device=device)
                              for _ in range(2)] if (self.rank == dst and self.world > 1) else [None, None]
@@ -160,10 +180,21 @@ class BatchExchange:
         b3 = step % 3
         assert step - 3 not in self.stage, "a batch's entries are still in flight: drain() or submit in order"
         dist, world = self.dist, self.world
+        if self.on_side and self.reusable[b3] is not None:
+            torch.cuda.current_stream().wait_event(self.reusable[b3])   # the gather of batch step - 3 has read entries[b3]
+            self.reusable[b3] = None
         self.compact(self.slabs[step & 1], self.entries[b3], self.count[b3])
-        st = dict(b3=b3, counts=None, work=None, nmax=None, gathered=None)
-        if world == 1:
+        st = dict(b3=b3, counts=None, work=None, nmax=None, gathered=None, ready=None)
+        if not self.collectives:
             st["counts"] = self.count[b3]
+        elif self.on_side:
+            st["counts"] = self.counts_all[b3]
+            work = dist.all_gather_into_tensor(st["counts"], self.count[b3], group=self.group, async_op=True)
+            with torch.cuda.stream(self.side):
+                work.wait()                              # the SIDE stream waits for the collective; the render stream goes on
+                self.counts_host[b3].copy_(st["counts"], non_blocking=True)
+                st["ready"] = torch.cuda.Event()
+                st["ready"].record()
         elif _staged(self.count[b3], dist, self.group):
             every = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
             dist.all_gather(every, self.count[b3].cpu(), group=self.group)
@@ -186,15 +217,25 @@ class BatchExchange:
         if st["work"] is not None:
             st["work"].wait()
             st["work"] = None
-        counts = [int(c) for c in st["counts"].tolist()]          # (host reads the device: later renders are queued)
+        if st["ready"] is not None:
+            st["ready"].synchronize()                 # the host waits for this batch's count exchange, for nothing queued since
+            counts = [int(c) for c in self.counts_host[st["b3"]].tolist()]
+        else:
+            counts = [int(c) for c in st["counts"].tolist()]
         if max(counts) > self.capacity:
             raise RuntimeError(f"sparse exchange: {max(counts)} occupied tiles exceed the capacity of {self.capacity}")
         nmax = st["nmax"] = max(counts)
         self.sent_bytes += nmax * self.entry_bytes + 4
         send = self.entries[st["b3"]][:max(nmax, 1)]
         dist, world = self.dist, self.world
-        if world == 1:
+        if not self.collectives:
             st["gathered"] = send.unsqueeze(0)
+        elif self.on_side:
+            with torch.cuda.stream(self.side):        # (RCCL's stream waits for the stream the call is made on)
+                if self.rank == self.dst:
+                    st["gathered"] = torch.empty((world, max(nmax, 1), self.entry_bytes), dtype=torch.uint8, device=send.device)
+                st["work"] = dist.gather(send, list(st["gathered"].unbind(0)) if self.rank == self.dst else None,
+                                         dst=self.dst, group=self.group, async_op=True)
         elif _staged(send, dist, self.group):
             host = send.cpu()
             parts = [torch.empty_like(host) for _ in range(world)] if self.rank == self.dst else None
@@ -212,6 +253,17 @@ class BatchExchange:
         if st is None:
             return
         self._gather_stage(step)
+        if self.on_side:
+            import torch
+            with torch.cuda.stream(self.side):
+                st["work"].wait()
+                if self.rank == self.dst:
+                    self.place_tiles(st["gathered"], st["counts"], step)
+                # entries[b3] (read by the gather) and counts_all[b3] (read by the placement) may be written again after this
+                self.reusable[st["b3"]] = torch.cuda.Event()
+                self.reusable[st["b3"]].record()
+            del self.stage[step]
+            return
         if st["work"] is not None:
             st["work"].wait()
         del self.stage[step]
@@ -222,6 +274,9 @@ class BatchExchange:
         if self.sparse:
             for step in sorted(self.stage):
                 self._place_stage(step)
+            if self.on_side:
+                import torch
+                torch.cuda.current_stream().wait_stream(self.side)   # what follows on the render stream sees the frames
             return
         # in submission order
         order = sorted((p[1], b) for b, p in enumerate(self.pending) if p is not None)

@@ -68,6 +68,7 @@ class Renderer:
         torch = _torch()
         s = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self._L.rt_set_stream(self._h, ctypes.c_void_p(s), 0))
+        self._stream = s
 
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))
@@ -281,10 +282,20 @@ class Renderer:
         self._check(self._L.rt_compact_tiles(self._h, slab.data_ptr(), entries.data_ptr(), count.data_ptr(),
                                              int(entries.shape[0])))
 
-    def place_tiles(self, entries, counts, width, height, tile_rows, out, table=None):
+    def place_tiles(self, entries, counts, width, height, tile_rows, out, table=None, on_current_stream=False):
         """Root side (rt_place_tiles): gathered ``entries`` uint8 [n_ranks, capacity, TILE_ENTRY_BYTES] and ``counts``
-        (device, 32-bit, [n_ranks]) -> ``out`` uint8 [F, H, W, 3], black where no entry covers a tile."""
+        (device, 32-bit, [n_ranks]) -> ``out`` uint8 [F, H, W, 3], black where no entry covers a tile.
+        ``on_current_stream``: launch on torch's current stream for this call only (BatchExchange places on its side
+        stream, beside the renders of later batches), then go back to the stream of use_torch_stream()."""
         torch = _torch()
+        if on_current_stream:
+            mine = self._stream
+            self.use_torch_stream()
+            try:
+                return self.place_tiles(entries, counts, width, height, tile_rows, out, table)
+            finally:
+                self._check(self._L.rt_set_stream(self._h, ctypes.c_void_p(mine), 0))
+                self._stream = mine
         from .tiling import max_local_rows
         n_ranks, cap = int(entries.shape[0]), int(entries.shape[1])
         nf = int(out.shape[0])

@@ -32,6 +32,8 @@ def test_no_alloc_entry_point_matches_rt_render():
     L = _lib.load()
     h = ctypes.c_void_p()
     assert L.rt_create(0, ctypes.byref(h)) == 0
+    # the context launches on torch's current stream, so the fills below, the renders and the comparisons are ordered
+    assert L.rt_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream(0).cuda_stream), 0) == 0
     try:
         def both(w, hh, D, mode, seed, cam):
             c = RtCamera.from_camera(cam)
@@ -80,3 +82,36 @@ def test_no_alloc_entry_point_matches_rt_render():
         assert L.rt_render_noalloc(h, ctypes.byref(c), 64, 48, 1, 5, 1, 0, None, None) == -1
     finally:
         L.rt_destroy(h)
+
+
+def test_no_alloc_entry_point_allocates_nothing():
+    """A fresh context whose FIRST render call is rt_render_noalloc (nothing has grown the context's own buffers, so a
+    call that used them instead of the scratch array would fault or fail), with the device's free memory unchanged
+    across the calls; the frame equals rt_render's on another context."""
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    L = _lib.load()
+    h, h2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.rt_create(0, ctypes.byref(h)) == 0 and L.rt_create(0, ctypes.byref(h2)) == 0
+    stream = ctypes.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    assert L.rt_set_stream(h, stream, 0) == 0 and L.rt_set_stream(h2, stream, 0) == 0
+    try:
+        scene = generate_scene(8, 1, keep_default=True)
+        _upload(L, h, scene)
+        _upload(L, h2, scene)
+        c = RtCamera.from_camera(None)
+        out = torch.zeros((2, 540, 960, 3), dtype=torch.uint8, device="cuda:0")
+        ref = torch.zeros((540, 960, 3), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info(0)
+        for i in range(2):
+            assert L.rt_render_noalloc(h, ctypes.byref(c), 960, 540, 1, 5, 1, 7, out[i].data_ptr(), None) == 0, L.rt_last_error(h)
+        assert L.rt_synchronize(h) == 0
+        free1, _ = torch.cuda.mem_get_info(0)
+        assert free1 == free0, (free0, free1)
+        assert L.rt_render(h2, ctypes.byref(c), 960, 540, 1, 5, 1, 7, ref.data_ptr(), None) == 0
+        assert L.rt_synchronize(h2) == 0
+        assert torch.equal(out[0], ref) and torch.equal(out[1], ref) and int(ref.max()) > 9
+    finally:
+        L.rt_destroy(h)
+        L.rt_destroy(h2)
