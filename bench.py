@@ -73,6 +73,7 @@ WORKLOADS = {
     "cubes": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene() (default scene + 3 opaque cubes) 1920x1080 depth 5"),
     "cubes_glass": (1920, 1080, 6, 0, True, 5, "8f rank 3: cube_scene(glass=True) 1920x1080 depth 5"),
     "refr40": (1920, 1080, 40, 12, False, 5, "8f rank 2: 40 generated spheres, every third of glass, 1920x1080 depth 5"),
+    "c2g": (1920, 1080, 8, 1, True, 5, "diagnostic: config 2 plus one glass sphere behind the camera, which no ray meets (the refractive kernels on config 2's rays)"),
 }
 
 
@@ -89,6 +90,10 @@ def build_scene(wl):
     if wl in ("refr", "cubes", "cubes_glass"):
         return refractive_scene() if wl == "refr" else cube_scene(glass=(wl == "cubes_glass"))
     scene = default_scene() if n == 3 else generate_scene(n, sseed, w, h, keep_default=keep)
+    if wl == "c2g":
+        from raytracer_amd.scenes import Material, Sphere, Vector3
+        scene["spheres"].append(Sphere(Vector3(0.0, 0.0, 60.0), 1.0, Material(Vector3(1, 1, 1), specular=0.5, reflection=0.0,
+                                                                              refraction=0.5, refractive_index=1.5)))
     if wl == "refr40":
         for i, s_ in enumerate(scene["spheres"]):
             if i % 3 == 0:

@@ -223,6 +223,9 @@ constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (ra
 #ifndef RT_REFR_BATCH
 #define RT_REFR_BATCH 7
 #endif
+#ifndef RT_REFR_WAVES
+#define RT_REFR_WAVES 4     // waves per SIMD the REFR slot variants are compiled for (their LDS holds three workgroups per CU)
+#endif
 constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: two verdicts per ray (opaque / glass), so fewer rays per batch fit the registers
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
@@ -952,6 +955,11 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if RT_LIGHT_FAST & 2
   const float nrx = -fmaf(2.0f * vdn, nx, dx), nry = -fmaf(2.0f * vdn, ny, dy), nrz = -fmaf(2.0f * vdn, nz, dz);
 #endif
+  // REFR (its rays come in several batches): the spheres 0..63 / boxes 0..31 that the FIRST batch's culls let through.  That
+  // batch holds the point-light ray, so its survivors are a superset of every later batch's: the later batches test these
+  // without culling again, and a ray that hits objects of BOTH kinds finds its nearest hit among them (no other object can
+  // be hit by any of the point's shadow rays).
+  [[maybe_unused]] uint32_t kept0 = 0u, kept1 = 0u, keptc = 0u;
   for (int base = 0; base < nrays; base += B) {
     float Lx[B], Ly[B], Lz[B], m[B];
     float mrf[REFR ? B : 1];   // REFR: the same verdicts for the REFRACTIVE spheres (m: the opaque ones)
@@ -1126,6 +1134,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         // spheres reach into it).  Lanes shade different objects, so each walks its own bit list.
         uint32_t cand = occl_row[word];
         uint32_t rel = 0u;
+        if (REFR && base > 0 && n <= 64) { cand = 0u; rel = word == 0 ? kept0 : kept1; }   // (the first batch's survivors)
         while (__ballot(cand != 0u) != 0ull) {
 #if RT_CULL_STATS
           g_dbg_turns += 1;
@@ -1159,6 +1168,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if RT_CULL_STATS
         g_dbg_rel += __popc(rel); g_dbg_lanes += 1;
 #endif
+        if constexpr (REFR) { if (base == 0) { if (word == 0) kept0 = rel; else if (word == 1) kept1 = rel; } }
         while (__ballot(rel != 0u) != 0ull) {
 #if RT_CULL_STATS
           g_dbg_iters += 1;
@@ -1221,7 +1231,9 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       for (int c0 = 0; c0 < nc; c0 += 32) {
         uint32_t cm = 0u;
         const int cn = min(32, nc - c0);
-        for (int c = 0; c < cn; ++c) {
+        const bool again = REFR && base > 0 && nc <= 32;       // (the first batch's candidate boxes)
+        if (again) cm = keptc;
+        for (int c = 0; c < (again ? 0 : cn); ++c) {
           const float4 lo = sg[n + 2 * (c0 + c)], hi = sg[n + 2 * (c0 + c) + 1];      // wave-uniform: LDS broadcast
           const float hx = 0.5f * (hi.x - lo.x), hy = 0.5f * (hi.y - lo.y), hz = 0.5f * (hi.z - lo.z);
           const float cx = (lo.x + hx) - sx, cy = (lo.y + hy) - sy, cz = (lo.z + hz) - sz;
@@ -1241,6 +1253,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if !RT_CUBE_SHADOW_CULL
         cm = cn >= 32 ? ~0u : (1u << cn) - 1u;      // (diagnostic build: every box for every lane — tools/fuzz_cubes.py)
 #endif
+        if constexpr (REFR) { if (c0 == 0 && base == 0) keptc = cm; }
         while (__ballot(cm != 0u) != 0ull) {
           if (cm != 0u) {
             const int c = c0 + __ffs(int(cm)) - 1;
@@ -1298,17 +1311,56 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       // candidates, no root taken.  No opaque hit: lit.  Opaque hits only: blocked.  Both (a ray through glass
       // towards something solid, or the other way round: rare): the nearest hit decides, found by the full scan
       // of find_nearest_intersection for that ray.  Cubes (their line rule, :137, :162) have been entered into m and mrf above.
+      // (sign bits as truth values, as in the scan: m / mrf have their sign CLEAR where an opaque / a refractive object was
+      // hit; lit <=> no opaque hit or some refractive one <=> sign of m | ~mrf set: two operations per ray.  Whether any ray
+      // of the lane was hit by objects of BOTH kinds — sign of m | mrf clear — is asked once per batch.)
+      uint32_t both_any = 0u;
 #pragma unroll
       for (int k = 0; k < B; ++k) {
-        bool solid = int(__float_as_uint(m[k])) >= 0, glass = int(__float_as_uint(mrf[k])) >= 0;
-        bool blocked = solid && !glass;
-        if (solid && glass && base + k < nrays) {
-          float t;
-          int hi, face;
-          nearest_object<CUBES>(sg, gg, n, nc, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi, face);
-          blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
+        const uint32_t ms = __float_as_uint(m[k]), gs = __float_as_uint(mrf[k]);
+        m[k] = __uint_as_float(ms | ~gs);                        // sign set: lit (what the weights below look at)
+        mrf[k] = __uint_as_float(ms | gs);                       // sign clear: both kinds
+        both_any |= ~(ms | gs);
+        asm volatile("" : "+v"(both_any));
+      }
+      if (__ballot(int(both_any) < 0) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          if (int(__float_as_uint(mrf[k])) >= 0 && base + k < nrays) {
+            float t = INFINITY;
+            int hi = -1, face;
+            if (n <= 64 && nc <= 32) {
+              // (the expressions and the order of nearest_object(): the same distances, the lowest index on a tie, spheres
+              // before boxes — over the point's surviving candidates instead of every object of the scene)
+              const float inv_a = frcp(fmaf(Lz[k], Lz[k], fmaf(Ly[k], Ly[k], Lx[k] * Lx[k])));
+              uint32_t lo = kept0, up = kept1;
+              while ((lo | up) != 0u) {
+                const bool in_lo = lo != 0u;
+                uint32_t cur = in_lo ? lo : up;
+                const int j = (in_lo ? 0 : 32) + __ffs(int(cur)) - 1;
+                cur &= cur - 1u;
+                if (in_lo) lo = cur; else up = cur;
+                float dl;
+                const float tt = sphere_t_exact(sg[j], sx, sy, sz, Lx[k], Ly[k], Lz[k], inv_a, dl);
+                if (dl >= 0.0f && tt > 0.0f && tt < t) { t = tt; hi = j; }
+              }
+              if constexpr (CUBES) {
+                const float ix = frcp(Lx[k]), iy = frcp(Ly[k]), iz = frcp(Lz[k]);
+                uint32_t cmk = keptc;
+                while (cmk != 0u) {
+                  const int c = __ffs(int(cmk)) - 1;
+                  cmk &= cmk - 1u;
+                  float tc;
+                  if (cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], sx, sy, sz, Lx[k], Ly[k], Lz[k], ix, iy, iz, tc, face) && tc < t) { t = tc; hi = n + c; }
+                }
+              }
+            } else {
+              nearest_object<CUBES>(sg, gg, n, nc, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi, face);
+            }
+            const bool blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
+            m[k] = blocked ? 0.0f : -1.0f;
+          }
         }
-        m[k] = blocked ? 0.0f : -1.0f;
       }
     }
 #pragma unroll
@@ -2019,10 +2071,10 @@ constexpr int kSlotHdr = 4;                                 // words: tx | ty <<
 // to run and from tiling to tiling (float atomics into a slab in device memory, the earlier form, gave neither
 // repeatable bytes nor acceptable write traffic: 22 x the frame's bytes on glass cubes).
 #ifndef RT_TILE_SLOTS_REFR
-#define RT_TILE_SLOTS_REFR 4
+#define RT_TILE_SLOTS_REFR 3     // (2 .. 5 measure the same within 1 %: older records are shaded first, so few tiles are in flight)
 #endif
 constexpr int kTileSlotsRefr = RT_TILE_SLOTS_REFR;
-static_assert(kTileSlotsRefr >= 2 && kTileSlotsRefr <= 4, "four 16-bit record counts in one scalar register pair");
+static_assert(kTileSlotsRefr >= 2 && kTileSlotsRefr <= 5, "five 12-bit record counts in one scalar register pair");
 constexpr float kSumScale = 16777216.0f;                    // 2^24: a sum saturates at 256 (x samples <= 64: the mean still clamps to 1)
 constexpr int tile_slots(int out, bool refr = false) {
   return refr ? kTileSlotsRefr : out >= 3 ? RT_TILE_SLOTS_MULTI_SMALL : out == 2 ? kTileSlotsMulti : kTileSlots;
@@ -2041,7 +2093,7 @@ __device__ __forceinline__ int meta_slotpix(uint32_t m) { return int((m >> 7) & 
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
 constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
-constexpr int ring_of(int out) { return out >= 3 ? 1 : kRing; }   // (one entry costs the one-sample path 9 %; OUT = 3 buys a workgroup per CU with it)
+constexpr int ring_of(int out, int refr = 0) { return (out >= 3 || (refr && out)) ? 1 : kRing; }   // (one entry costs the opaque one-sample path 9 %; OUT = 3 and the refractive slot kernels buy a workgroup per CU with it)
 #ifndef RT_CLAIM
 #define RT_CLAIM 32    // slots per claim at most: one occupancy word's worth
 #endif
@@ -2053,18 +2105,28 @@ constexpr int kClaimMax = RT_CLAIM;
 #define RT_GUIDE 2      // a claim is 1/(RT_GUIDE x waves per counter) of what its counter has left
 #endif
 
-constexpr int kBounceCapRefr = 192;                   // refraction: RT_MAX_DEPTH + 2 x 64, see the pass sizing in the kernel
+// Refraction: a lane may push two records, so the queue is longer: max_depth + 2 x 64 (see the pass sizing in the kernel).
+// Two kinds of refractive kernels (the REFR template argument): 1 = max_depth <= kRefrShallowDepth, 160 records — with three
+// tile slots and one ring entry 9.5 KB of LDS per wave, FOUR workgroups per CU; 2 = any depth up to RT_MAX_DEPTH, 192 records,
+// three workgroups per CU.  (The kernel's progress per wave hardly depends on how many waves share a SIMD — dependent
+// chains and LDS round trips, not issue slots, pace a wave — so a fourth workgroup is worth a third more frames: config 2's
+// rays through the refractive kernels took 1.33 x as long on three as on four.)
+constexpr int kRefrShallowDepth = 32;
+constexpr int kBounceCapRefrShallow = kRefrShallowDepth + 2 * 64;
+constexpr int kBounceCapRefr = RT_MAX_DEPTH + 2 * 64;
+constexpr int bounce_cap(int refr) { return refr == 2 ? kBounceCapRefr : refr == 1 ? kBounceCapRefrShallow : 128; }
 // Refraction: the fields a record carries (no acc: nodes add into the pixel sums), in the order they are set aside
 constexpr int kSpillFields = 12;                     // (the most: a block holds whole records of 11 or 12 fields)
 static_assert(kSpillFields == kQueueFieldsRefr && kQueueFieldsRefrSlots <= kSpillFields, "a spill block holds whole records");
 constexpr int kSpillBlocksMax = 32;                   // blocks of 64 records a wave may have set aside (3 KB each)
+static_assert(kBounceCapRefr + kSpillBlocksMax * 64 < 4096, "a slot's count of live records takes 12 bits");
 template <int CAP>
 struct Queue {
   float* f;        // kQueueFields arrays of CAP words (field-major: conflict-free lane access)
   __device__ __forceinline__ float& at(int field, int i) const { return f[field * CAP + i]; }
 };
-constexpr int wave_lds_bytes(bool refr, int out = 0) {
-  return queue_fields(refr, out) * (refr ? kBounceCapRefr : kBounceCap) * 4 + ring_of(out) * kVisTile * 2 + slot_bytes(out, refr);
+constexpr int wave_lds_bytes(int refr, int out = 0) {
+  return queue_fields(refr != 0, out) * bounce_cap(refr) * 4 + ring_of(out, refr) * kVisTile * 2 + slot_bytes(out, refr != 0);
 }
 
 // LDS accesses of one wave are executed in program order; this only stops the compiler from moving
@@ -2110,22 +2172,23 @@ __device__ __forceinline__ void queue_take_back(float* qf, const float* src, int
 // LDS for three workgroups per CU, one per eight waves for two of twice the size (config 4: 308 -> 334 Grays/s).
 // (Before that, 2 was the four-wave form compiled for three waves per SIMD — 156 VGPRs, nothing spilled: 271 -> 281.)
 // 3 = SIXTEEN waves around one copy (from ~1100 spheres on, where two eight-wave workgroups no longer fit a CU).
-template <int MODE, bool REFR, bool CUBES, int GRID = 0, int OUT = 0>
-__global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock), (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+template <int MODE, int REFR, bool CUBES, int GRID = 0, int OUT = 0>
+__global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock), (OUT == 2) ? 3 : (REFR && OUT == 1) ? RT_REFR_WAVES : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
   constexpr int kThreads = GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock;
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
   constexpr bool SUMS = MULTI || (REFR && SLOTS);     // a slot holds three sums per pixel (else one RGBX word)
-  constexpr int kRing = ring_of(OUT);
+  constexpr int kRing = ring_of(OUT, REFR);
   static_assert(GRID == 0 || (!REFR && !CUBES), "the grid variant exists for sphere-only opaque scenes");
   static_assert(!REFR || OUT <= 2, "refractive scenes: scattered sums (0), tile slots (1), all samples in one launch (2)");
-  constexpr int kCap = REFR ? kBounceCapRefr : kBounceCap;
+  constexpr int kCap = bounce_cap(REFR);
+  static_assert(kBounceCap == bounce_cap(0), "opaque scenes: a pass takes 64 records and pushes at most 64");
   constexpr int kWaveLdsBytes = wave_lds_bytes(REFR, OUT);
   constexpr int kFields = queue_fields(REFR, OUT);
-  constexpr int kSlots = tile_slots(OUT, REFR);
+  constexpr int kSlots = tile_slots(OUT, REFR != 0);
   // what a slot still waits for, one count per slot in a scalar register pair: hit pixels of the tile (at most 64: a byte),
-  // or — REFR — records of its pixels' trees that are alive in the queue or the spill stack (at most kCap + 32 x 64: 16 bits)
-  constexpr int kCntBits = REFR ? 16 : 8;
+  // or — REFR — records of its pixels' trees that are alive in the queue or the spill stack (at most kCap + 32 x 64 = 2240: 12 bits)
+  constexpr int kCntBits = REFR ? 12 : 8;
   static_assert(kSlots * kCntBits <= 64, "the slots' counts share one scalar register pair");
   extern __shared__ __align__(16) unsigned char smem[];
   float4* sg = reinterpret_cast<float4*>(smem);                                // spheres, then cubes (2 entries each)
@@ -2528,7 +2591,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
         // touches positions l, 64 + l and 128 + l only, so the move needs no ordering between lanes.
         // Positions only decrease, so the bound above still holds; when the stack is full (spill_blocks)
         // the rule above alone keeps the queue within kCap.
-        static_assert(kCap >= RT_MAX_DEPTH + 2 * 64, "a tile's fresh hits must fit below the high-water mark");
+        static_assert(kCap >= (REFR == 1 ? kRefrShallowDepth : RT_MAX_DEPTH) + 2 * 64, "a tile's fresh hits must fit below the high-water mark");
         static_assert(kCap <= 3 * 64, "the move below handles three rows of 64 records");
         const RenderParams& p = params_here();
         const int high = kCap - p.max_depth;
@@ -2740,13 +2803,16 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             const unsigned long long same = __ballot(have && fslot == k);
             todo &= ~same;
             const long long delta = (long long)(__popcll(mask_r & same) + __popcll(mask_f & same)) - (long long)__popcll(same);
-            slot_left += (unsigned long long)(delta << (kCntBits * k));      // (the field stays within 0 .. 65535: no borrow)
+            slot_left += (unsigned long long)(delta << (kCntBits * k));      // (the field stays within 0 .. 4095: no borrow)
             if (((slot_left >> (kCntBits * k)) & ((1ull << kCntBits) - 1ull)) == 0ull) complete |= 1u << k;
           }
           if (complete != 0u) flush_slots(complete);
         }
         const unsigned long long s3 = RT_NOW();
         st_pop += s1 - s0; st_light += s2 - s1; st_near += s3 - s2;
+#if RT_STAMPS
+        st_passes += 1; st_lanes += unsigned(nb); st_starved += (nb < 64 && !done) ? 1u : 0u;
+#endif
         continue;
       }
       if (have) {
@@ -3265,7 +3331,7 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
-size_t stream_lds(int n_spheres, bool refr = false, int out = 0, int waves = kBlock / 64) {
+size_t stream_lds(int n_spheres, int refr = 0, int out = 0, int waves = kBlock / 64) {
   return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * size_t(waves);
 }
 // resident workgroups of the stream kernel per CU: one per wave slot of a SIMD, or as many as 160 KB of LDS hold
@@ -3567,7 +3633,8 @@ RenderKernel pick_visibility_kernel(int rng_mode, bool cubes, bool multi = false
 //   sums), 1 = tile slots, 2 = all samples of a pixel in one launch, 3 / 4 = the same with three slots (four-wave /
 //   eight-wave workgroups)
 struct StreamVariant {
-  bool refr, cubes;
+  int refr;      // 0 = opaque scene, 1 = refractive (max_depth <= kRefrShallowDepth), 2 = refractive, any depth
+  bool cubes;
   int grid, out;
   RenderKernel keyed, constant;
 };
@@ -3575,19 +3642,19 @@ struct StreamVariant {
   {R, C, G, O, rt_stream_kernel<RT_RNG_KEYED, R, C, G, O>, rt_stream_kernel<RT_RNG_CONSTANT, R, C, G, O>}
 const StreamVariant kStreamVariants[] = {
     // opaque scenes
-    RT_STREAM_VARIANT(false, false, 0, 0), RT_STREAM_VARIANT(false, true, 0, 0),
-    RT_STREAM_VARIANT(false, false, 1, 0), RT_STREAM_VARIANT(false, false, 2, 0), RT_STREAM_VARIANT(false, false, 3, 0),
-    RT_STREAM_VARIANT(false, false, 0, 1), RT_STREAM_VARIANT(false, true, 0, 1),
-    RT_STREAM_VARIANT(false, false, 1, 1), RT_STREAM_VARIANT(false, false, 2, 1), RT_STREAM_VARIANT(false, false, 3, 1),
-    RT_STREAM_VARIANT(false, false, 0, 2), RT_STREAM_VARIANT(false, true, 0, 2), RT_STREAM_VARIANT(false, false, 1, 2),
-    RT_STREAM_VARIANT(false, false, 0, 3), RT_STREAM_VARIANT(false, true, 0, 3),
-    RT_STREAM_VARIANT(false, false, 0, 4), RT_STREAM_VARIANT(false, true, 0, 4),
-    // refractive scenes: float sums in device memory (0), fixed-point sums in tile slots (1)
-    RT_STREAM_VARIANT(true, false, 0, 0), RT_STREAM_VARIANT(true, true, 0, 0),
-    RT_STREAM_VARIANT(true, false, 0, 1), RT_STREAM_VARIANT(true, true, 0, 1),
+    RT_STREAM_VARIANT(0, false, 0, 0), RT_STREAM_VARIANT(0, true, 0, 0),
+    RT_STREAM_VARIANT(0, false, 1, 0), RT_STREAM_VARIANT(0, false, 2, 0), RT_STREAM_VARIANT(0, false, 3, 0),
+    RT_STREAM_VARIANT(0, false, 0, 1), RT_STREAM_VARIANT(0, true, 0, 1),
+    RT_STREAM_VARIANT(0, false, 1, 1), RT_STREAM_VARIANT(0, false, 2, 1), RT_STREAM_VARIANT(0, false, 3, 1),
+    RT_STREAM_VARIANT(0, false, 0, 2), RT_STREAM_VARIANT(0, true, 0, 2), RT_STREAM_VARIANT(0, false, 1, 2),
+    RT_STREAM_VARIANT(0, false, 0, 3), RT_STREAM_VARIANT(0, true, 0, 3),
+    RT_STREAM_VARIANT(0, false, 0, 4), RT_STREAM_VARIANT(0, true, 0, 4),
+    // refractive scenes: float sums in device memory (0), fixed-point sums in tile slots (1); queues of 160 / 192 records
+    RT_STREAM_VARIANT(1, false, 0, 0), RT_STREAM_VARIANT(1, true, 0, 0), RT_STREAM_VARIANT(2, false, 0, 0), RT_STREAM_VARIANT(2, true, 0, 0),
+    RT_STREAM_VARIANT(1, false, 0, 1), RT_STREAM_VARIANT(1, true, 0, 1), RT_STREAM_VARIANT(2, false, 0, 1), RT_STREAM_VARIANT(2, true, 0, 1),
 };
 #undef RT_STREAM_VARIANT
-RenderKernel pick_stream_kernel(int rng_mode, bool refr, bool cubes, int grid = 0, int out = 0) {
+RenderKernel pick_stream_kernel(int rng_mode, int refr, bool cubes, int grid = 0, int out = 0) {
   for (const StreamVariant& v : kStreamVariants)
     if (v.refr == refr && v.cubes == cubes && v.grid == grid && v.out == out)
       return rng_mode == RT_RNG_KEYED ? v.keyed : v.constant;
@@ -3629,6 +3696,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // (the kernels count tiles of a batch in 32-bit integers)
   const long long frame_tiles = (long long)(((w.nx + 7) / 8) | 1) * ((w.n_rows + 7) / 8);   // tile ids per frame (odd pitch)
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
+  const int refr_kind = refr ? (max_depth > kRefrShallowDepth ? 2 : 1) : 0;   // which refractive kernels: queue of 160 / 192 records
   // Refractive scenes, 8-bit frames at one sample per pixel: the stream kernel sums a pixel's tree in its tile's slot
   // (fixed point: needs shares that are never negative, which rt_upload_scene / rt_set_refraction / rt_set_cubes have
   // checked).  Otherwise (float output, several samples, RT_OPT_TILE_FLUSH off, a scene with negative colours) every node
@@ -3833,7 +3901,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   }
   for (int f0 = 0; f0 < n_frames; f0 += max_batch) {
     const int nf = std::min(max_batch, n_frames - f0);
-    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, slots, wg_waves) : pixel_lds(ctx->n_spheres);
+    const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr_kind, slots, wg_waves) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = d_frames;
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
@@ -3884,7 +3952,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         hipLaunchKernelGGL(pick_visibility_kernel(rng_mode, cubes, multi, ctx->n_spheres > 64), vgrid, dim3(RT_VIS_BLOCK), vlds, ctx->stream, p);
         // (MULTI: one visibility launch per sample, then ONE stream-kernel launch that shades them all)
         if (!multi || s + 1 == samples) {
-          const RenderKernel shade = pick_stream_kernel(rng_mode, refr, cubes, list_kernel, slots);
+          const RenderKernel shade = pick_stream_kernel(rng_mode, refr_kind, cubes, list_kernel, slots);
           if (!shade) return fail(ctx, RT_ESTATE, "no stream kernel variant for refr %d cubes %d lists %d output %d", int(refr), int(cubes), list_kernel, slots);
           hipLaunchKernelGGL(shade, sgrid, dim3(threads), lds, ctx->stream, p);
         }

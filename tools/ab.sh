@@ -3,7 +3,7 @@
 wls=$1; shift
 for lib in "$@"; do
   for wl in $wls; do
-    RT355_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-target --workload $wl ${AB_ARGS:-} 2>&1 | tail -1 | python -c "
+    RT355_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-target --no-single-frame --batches ${AB_BATCHES:-1} --workload $wl ${AB_ARGS:-} 2>&1 | tail -1 | python -c "
 import sys, json
 l=sys.stdin.read().strip()
 try:

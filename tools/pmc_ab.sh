@@ -12,7 +12,7 @@ for lib in "$@"; do
              "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" \
              "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAIT_ANY"; do
     i=$((i+1))
-    (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc $pmc --output-format csv -d "$out/pass$i" -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target --workload $wl > "$out/pass$i.log" 2>&1) || { echo "pass $i failed"; tail -3 "$out/pass$i.log"; exit 1; }
+    (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc $pmc --output-format csv -d "$out/pass$i" -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target --no-single-frame --batches ${AB_BATCHES:-1} --workload $wl > "$out/pass$i.log" 2>&1) || { echo "pass $i failed"; tail -3 "$out/pass$i.log"; exit 1; }
   done
 done
 python3 - "$root/gpurun_out/pmc_ab" <<'PY'

@@ -6,7 +6,7 @@ tag=${1:-r1}; shift || true
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-target $*"
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --batches 1 --no-cpu-baseline --no-target --no-single-frame $*"
 cd /tmp
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $BENCH > "$out/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$out/trace.log"; exit 1; }
 i=0
