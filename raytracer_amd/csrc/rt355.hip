@@ -226,6 +226,18 @@ constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (ra
 #ifndef RT_REFR_WAVES
 #define RT_REFR_WAVES 4     // waves per SIMD the REFR slot variants are compiled for (their LDS holds three workgroups per CU)
 #endif
+// Scenes with boxes: 13 rays at a time (7 with refraction) left the shading kernels 34 VGPRs short — scratch traffic of
+// 1.2e10 bytes per 1024 frames on cube_scene(), 1.4e11 with glass (TCC_EA0_WRREQ; round 2 took the latter for the float
+// atomics' doing).  Batches of 7 / 5 fit the registers (no scratch); the later batches reuse the first one's cull.
+// cube_scene() 328 -> 376 Grays/s, with glass 235 -> 259 (9 / 7: 339 / 236, 5 / 4: 352 / 247).
+#ifndef RT_CUBE_BATCH
+#define RT_CUBE_BATCH 7
+#endif
+#ifndef RT_REFR_CUBE_BATCH
+#define RT_REFR_CUBE_BATCH 5
+#endif
+constexpr int kCubeShadowBatch = RT_CUBE_BATCH;            // scenes with boxes
+constexpr int kRefrCubeShadowBatch = RT_REFR_CUBE_BATCH;   // ... and refractive materials
 constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: two verdicts per ray (opaque / glass), so fewer rays per batch fit the registers
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
@@ -955,10 +967,11 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if RT_LIGHT_FAST & 2
   const float nrx = -fmaf(2.0f * vdn, nx, dx), nry = -fmaf(2.0f * vdn, ny, dy), nrz = -fmaf(2.0f * vdn, nz, dz);
 #endif
-  // REFR (its rays come in several batches): the spheres 0..63 / boxes 0..31 that the FIRST batch's culls let through.  That
+  // Rays in several batches (REFR, scenes with boxes): the spheres 0..63 / boxes 0..31 that the FIRST batch's culls let through.  That
   // batch holds the point-light ray, so its survivors are a superset of every later batch's: the later batches test these
   // without culling again, and a ray that hits objects of BOTH kinds finds its nearest hit among them (no other object can
   // be hit by any of the point's shadow rays).
+  constexpr bool SHARE = REFR || B < kShadowBatch;     // (the reference's 13 rays in one batch: nothing to share, no registers held)
   [[maybe_unused]] uint32_t kept0 = 0u, kept1 = 0u, keptc = 0u;
   for (int base = 0; base < nrays; base += B) {
     float Lx[B], Ly[B], Lz[B], m[B];
@@ -1134,7 +1147,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         // spheres reach into it).  Lanes shade different objects, so each walks its own bit list.
         uint32_t cand = occl_row[word];
         uint32_t rel = 0u;
-        if (REFR && base > 0 && n <= 64) { cand = 0u; rel = word == 0 ? kept0 : kept1; }   // (the first batch's survivors)
+        if (SHARE && base > 0 && n <= 64) { cand = 0u; rel = word == 0 ? kept0 : kept1; }   // (the first batch's survivors)
         while (__ballot(cand != 0u) != 0ull) {
 #if RT_CULL_STATS
           g_dbg_turns += 1;
@@ -1168,7 +1181,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if RT_CULL_STATS
         g_dbg_rel += __popc(rel); g_dbg_lanes += 1;
 #endif
-        if constexpr (REFR) { if (base == 0) { if (word == 0) kept0 = rel; else if (word == 1) kept1 = rel; } }
+        if constexpr (SHARE) { if (base == 0) { if (word == 0) kept0 = rel; else if (word == 1) kept1 = rel; } }
         while (__ballot(rel != 0u) != 0ull) {
 #if RT_CULL_STATS
           g_dbg_iters += 1;
@@ -1231,7 +1244,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       for (int c0 = 0; c0 < nc; c0 += 32) {
         uint32_t cm = 0u;
         const int cn = min(32, nc - c0);
-        const bool again = REFR && base > 0 && nc <= 32;       // (the first batch's candidate boxes)
+        const bool again = SHARE && base > 0 && nc <= 32;      // (the first batch's candidate boxes)
         if (again) cm = keptc;
         for (int c = 0; c < (again ? 0 : cn); ++c) {
           const float4 lo = sg[n + 2 * (c0 + c)], hi = sg[n + 2 * (c0 + c) + 1];      // wave-uniform: LDS broadcast
@@ -1253,7 +1266,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if !RT_CUBE_SHADOW_CULL
         cm = cn >= 32 ? ~0u : (1u << cn) - 1u;      // (diagnostic build: every box for every lane — tools/fuzz_cubes.py)
 #endif
-        if constexpr (REFR) { if (c0 == 0 && base == 0) keptc = cm; }
+        if constexpr (SHARE) { if (c0 == 0 && base == 0) keptc = cm; }
         while (__ballot(cm != 0u) != 0ull) {
           if (cm != 0u) {
             const int c = c0 + __ffs(int(cm)) - 1;
@@ -1440,7 +1453,7 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-  const LightSums w = lighting<MODE, kShadowBatch, false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr,
+  const LightSums w = lighting<MODE, (CUBES ? kCubeShadowBatch : kShadowBatch), false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr,
                                LIST ? p.occl_start + idx : p.occl + size_t(idx) * size_t(p.occl_words), p.occl_items, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                level_key);
   float4 m;
@@ -2071,7 +2084,8 @@ constexpr int kSlotHdr = 4;                                 // words: tx | ty <<
 // to run and from tiling to tiling (float atomics into a slab in device memory, the earlier form, gave neither
 // repeatable bytes nor acceptable write traffic: 22 x the frame's bytes on glass cubes).
 #ifndef RT_TILE_SLOTS_REFR
-#define RT_TILE_SLOTS_REFR 3     // (2 .. 5 measure the same within 1 %: older records are shaded first, so few tiles are in flight)
+#define RT_TILE_SLOTS_REFR 2     // (older records are shaded first, so few tiles are in flight: at four workgroups per CU two slots measured
+                                 // +2 % over three on the glass spheres and cubes, -1 % on 40 spheres; four slots cost the fourth workgroup: -17 %)
 #endif
 constexpr int kTileSlotsRefr = RT_TILE_SLOTS_REFR;
 static_assert(kTileSlotsRefr >= 2 && kTileSlotsRefr <= 5, "five 12-bit record counts in one scalar register pair");
@@ -2093,7 +2107,10 @@ __device__ __forceinline__ int meta_slotpix(uint32_t m) { return int((m >> 7) & 
 #define RT_RING 2     // 2, 4 and 8 measure the same since only occupied tiles are loaded
 #endif
 constexpr int kRing = RT_RING;             // tiles whose index data is in LDS or on its way there (power of two)
-constexpr int ring_of(int out, int refr = 0) { return (out >= 3 || (refr && out)) ? 1 : kRing; }   // (one entry costs the opaque one-sample path 9 %; OUT = 3 and the refractive slot kernels buy a workgroup per CU with it)
+#ifndef RT_RING_REFR
+#define RT_RING_REFR 2     // (one entry: -4 % on the glass scenes)
+#endif
+constexpr int ring_of(int out, int refr = 0) { return (refr && out) ? RT_RING_REFR : out >= 3 ? 1 : kRing; }   // (one entry costs the opaque one-sample path 9 %; OUT = 3 and the refractive slot kernels buy a workgroup per CU with it)
 #ifndef RT_CLAIM
 #define RT_CLAIM 32    // slots per claim at most: one occupancy word's worth
 #endif
@@ -2106,11 +2123,9 @@ constexpr int kClaimMax = RT_CLAIM;
 #endif
 
 // Refraction: a lane may push two records, so the queue is longer: max_depth + 2 x 64 (see the pass sizing in the kernel).
-// Two kinds of refractive kernels (the REFR template argument): 1 = max_depth <= kRefrShallowDepth, 160 records — with three
-// tile slots and one ring entry 9.5 KB of LDS per wave, FOUR workgroups per CU; 2 = any depth up to RT_MAX_DEPTH, 192 records,
-// three workgroups per CU.  (The kernel's progress per wave hardly depends on how many waves share a SIMD — dependent
-// chains and LDS round trips, not issue slots, pace a wave — so a fourth workgroup is worth a third more frames: config 2's
-// rays through the refractive kernels took 1.33 x as long on three as on four.)
+// Two kinds of refractive kernels (the REFR template argument): 1 = max_depth <= kRefrShallowDepth, 160 records — with two
+// tile slots 8.9 KB of LDS per wave, FOUR workgroups per CU; 2 = any depth up to RT_MAX_DEPTH, 192 records, three workgroups
+// per CU (measured on the glass scenes: three workgroups are 15 - 20 % slower than four).
 constexpr int kRefrShallowDepth = 32;
 constexpr int kBounceCapRefrShallow = kRefrShallowDepth + 2 * 64;
 constexpr int kBounceCapRefr = RT_MAX_DEPTH + 2 * 64;
@@ -2681,7 +2696,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             const int idx = meta_object(meta);
             surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
             sx = fmaf(nx, 0.001f, px); sy = fmaf(ny, 0.001f, py); sz = fmaf(nz, 0.001f, pz);
-            const LightSums lw = lighting<MODE, kRefrShadowBatch, true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl + size_t(idx) * size_t(p.occl_words), nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
+            const LightSums lw = lighting<MODE, (CUBES ? kRefrCubeShadowBatch : kRefrShadowBatch), true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl + size_t(idx) * size_t(p.occl_words), nullptr, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz,
                                     sx, sy, sz, mix(pixel_key, uint32_t(meta_level(meta) + 1)));
             // (material, record state and the meta word come in BEHIND the shadow loops, as in the opaque path:
             // the 13-ray batch leaves no registers for them)
