@@ -335,10 +335,10 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         # (refractive scenes whose pixel sums lie in device memory — several samples per pixel —: as many frames per launch
         # pair as fit 32 GiB of them, kRefrSumBytes in csrc/rt355.hip)
-        refr_slabs = packed.has_refraction and (samples != 1 or os.environ.get("RT_BENCH_NO_TILE_FLUSH"))
+        refr_slabs = packed.has_refraction and (samples > 64 or os.environ.get("RT_BENCH_NO_TILE_FLUSH"))
         per_launch = min(FRAMES_PER_LAUNCH, max(1, (32 << 30) // (12 * rows_max * w))) if refr_slabs else FRAMES_PER_LAUNCH
         n_local_frames = len(mine) if frame_parallel else F
-        one_stream_launch = samples == 1 or (2 <= samples <= 64 and not packed.has_refraction and args.kernel == "stream"
+        one_stream_launch = samples == 1 or (2 <= samples <= 64 and args.kernel == "stream"
                                              and not os.environ.get("RT_BENCH_NO_TILE_FLUSH"))
         launches_per_step = B * -(-n_local_frames // per_launch) * (1 if one_stream_launch else samples)
         # (with several batches per step the events also cover the other stream-ordered work between the pairs: the

@@ -91,6 +91,7 @@ struct DevLights {
 // 16 -> 64 frames +12 %, 64 -> 256 +15 %, 256 -> 1024 +4 %)
 constexpr int kMaxBatch = RT_FRAMES_PER_LAUNCH;
 constexpr long long kRefrSumBytes = 32ll << 30;   // refractive scenes: most memory the float pixel sums of a launch may take
+constexpr long long kVisRecordBytes = 24ll << 30; // 2 .. 64 samples in one launch: most memory the tile records of a launch may take
 struct CamGroup;               // primary-ray table entry (four spheres), defined with primary_hit
 static_assert(kMaxBatch <= 8192, "frame numbers travel in 13 bits of the work-queue records");
 static_assert(RT_MAX_SPHERES <= 4096 && RT_MAX_DEPTH < 127, "object index: 12 bits, level: 7 bits of a record's meta word");
@@ -2188,7 +2189,7 @@ __device__ __forceinline__ void queue_take_back(float* qf, const float* src, int
 // (Before that, 2 was the four-wave form compiled for three waves per SIMD — 156 VGPRs, nothing spilled: 271 -> 281.)
 // 3 = SIXTEEN waves around one copy (from ~1100 spheres on, where two eight-wave workgroups no longer fit a CU).
 template <int MODE, int REFR, bool CUBES, int GRID = 0, int OUT = 0>
-__global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock), (OUT == 2) ? 3 : (REFR && OUT == 1) ? RT_REFR_WAVES : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
+__global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock), (REFR && OUT) ? RT_REFR_WAVES : (OUT == 2) ? 3 : RT_WAVES_PER_SIMD) void rt_stream_kernel(const RenderParams) {
   constexpr int kThreads = GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 : kBlock;
   // (the argument block is read through params_here(), phase by phase: never as a whole)
   constexpr bool SLOTS = OUT != 0, MULTI = OUT >= 2;
@@ -3664,9 +3665,11 @@ const StreamVariant kStreamVariants[] = {
     RT_STREAM_VARIANT(0, false, 0, 2), RT_STREAM_VARIANT(0, true, 0, 2), RT_STREAM_VARIANT(0, false, 1, 2),
     RT_STREAM_VARIANT(0, false, 0, 3), RT_STREAM_VARIANT(0, true, 0, 3),
     RT_STREAM_VARIANT(0, false, 0, 4), RT_STREAM_VARIANT(0, true, 0, 4),
-    // refractive scenes: float sums in device memory (0), fixed-point sums in tile slots (1); queues of 160 / 192 records
+    // refractive scenes: float sums in device memory (0), fixed-point sums in tile slots (1: one sample per pixel, 2: 2 .. 64
+    // samples in one launch); queues of 160 / 192 records
     RT_STREAM_VARIANT(1, false, 0, 0), RT_STREAM_VARIANT(1, true, 0, 0), RT_STREAM_VARIANT(2, false, 0, 0), RT_STREAM_VARIANT(2, true, 0, 0),
     RT_STREAM_VARIANT(1, false, 0, 1), RT_STREAM_VARIANT(1, true, 0, 1), RT_STREAM_VARIANT(2, false, 0, 1), RT_STREAM_VARIANT(2, true, 0, 1),
+    RT_STREAM_VARIANT(1, false, 0, 2), RT_STREAM_VARIANT(1, true, 0, 2), RT_STREAM_VARIANT(2, false, 0, 2), RT_STREAM_VARIANT(2, true, 0, 2),
 };
 #undef RT_STREAM_VARIANT
 RenderKernel pick_stream_kernel(int rng_mode, int refr, bool cubes, int grid = 0, int out = 0) {
@@ -3712,16 +3715,22 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const long long frame_tiles = (long long)(((w.nx + 7) / 8) | 1) * ((w.n_rows + 7) / 8);   // tile ids per frame (odd pitch)
   const bool refr = ctx->has_refr || ctx->has_refr_cubes;
   const int refr_kind = refr ? (max_depth > kRefrShallowDepth ? 2 : 1) : 0;   // which refractive kernels: queue of 160 / 192 records
-  // Refractive scenes, 8-bit frames at one sample per pixel: the stream kernel sums a pixel's tree in its tile's slot
+  // Refractive scenes, 8-bit frames at up to 64 samples per pixel: the stream kernel sums a pixel's trees in its tile's slot
   // (fixed point: needs shares that are never negative, which rt_upload_scene / rt_set_refraction / rt_set_cubes have
   // checked).  Otherwise (float output, several samples, RT_OPT_TILE_FLUSH off, a scene with negative colours) every node
   // adds into a float slab per frame (12 B per pixel) with float atomics, and a launch holds as many frames as fit
   // kRefrSumBytes of slabs (1024 at 1080p, 321 at 4K).
   const bool refr_slots = refr && ctx->kernel == RT_KERNEL_STREAM && ctx->tile_flush && ctx->sums_never_negative() && out_rgb &&
-                          !out_f32 && samples == 1;
+                          !out_f32 && samples <= 64;
   const int frames_cap = (refr && !refr_slots) ? int(std::max<long long>(1, std::min<long long>(kMaxBatch, kRefrSumBytes / (12 * std::max<long long>(win_px, 1)))))
                                                : kMaxBatch;
-  const int max_batch = int(std::max<long long>(1, std::min<long long>(frames_cap, (1ll << 30) / std::max<long long>(frame_tiles, 1))));
+  const bool stream_kernel_early = ctx->kernel == RT_KERNEL_STREAM;
+  const bool multi_early = stream_kernel_early && ctx->tile_flush && (!refr || refr_slots) && out_rgb && !out_f32 && samples >= 2 && samples <= 64;
+  // all samples of a pixel in one launch: the tile records have a sample dimension — 144 B per tile, frame and sample, 4.7 MB
+  // per 1080p frame and sample —, so a launch holds as many frames as fit kVisRecordBytes of them (1024 at 2 .. 5 samples,
+  // 81 at 64)
+  const long long multi_cap = multi_early ? std::max<long long>(1, kVisRecordBytes / (frame_tiles * kVisTile * 2 * samples)) : kMaxBatch;
+  const int max_batch = int(std::max<long long>(1, std::min<long long>(std::min<long long>(frames_cap, multi_cap), (1ll << 30) / std::max<long long>(frame_tiles, 1))));
   const int batch = std::min(n_frames, max_batch);
   const bool cubes = ctx->n_cubes > 0;
   if ((refr || cubes) && ctx->kernel != RT_KERNEL_STREAM)
@@ -3730,8 +3739,6 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     return fail(ctx, RT_EINVAL, "rt_render_noalloc renders one frame at one sample per pixel of a scene without refraction "
                                 "with the default kernel (samples %d, refractive %d): the other cases need buffers "
                                 "that are allocated on demand", samples, int(refr));
-  const bool stream_kernel_early = ctx->kernel == RT_KERNEL_STREAM;
-  const bool multi_early = stream_kernel_early && ctx->tile_flush && !refr && out_rgb && !out_f32 && samples >= 2 && samples <= 64;
   if ((samples > 1 && !multi_early) || (refr && !refr_slots)) {  // running sums over samples (and tree nodes), one slab per frame of a batch
     const size_t need = size_t(win_px) * 3 * size_t(batch);
     if (need > ctx->accum_floats) {
@@ -3761,8 +3768,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   const bool stream_kernel = ctx->kernel == RT_KERNEL_STREAM;
   // 8-bit frames at one sample per pixel: the stream kernel stages finished pixels per tile and stores whole tiles
   // ... and with 2..64 samples per pixel all of them are traced in ONE launch pair and summed in the slots
-  int slots = refr ? (refr_slots ? 1 : 0)
-                   : (stream_kernel && ctx->tile_flush && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
+  int slots = ((refr ? refr_slots : stream_kernel && ctx->tile_flush) && out_rgb && !out_f32) ? (samples == 1 ? 1 : samples <= 64 ? 2 : 0) : 0;
   // ... unless the slots' LDS would cost a resident workgroup per CU (many-sphere scenes, whose sphere list takes
   // 16 B per sphere of every workgroup's LDS): config 4 measured 88 Grays/s on three workgroups per CU with
   // scattered stores against 65 on two with tile stores
@@ -3788,11 +3794,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         if (stream_lds(ctx->n_spheres, false, sl, wv) <= size_t(160 * 1024) && waves > best) { best = waves; wg_waves = wv; slots = sl; }
       }
   }
-  if (slots == 2 && !listed && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3)) >
+  if (slots == 2 && !refr && !listed && workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3)) >
                                    workgroups_per_cu(stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 2)))
     slots = 3;
   // ... or, up to 72 spheres, as two workgroups of eight waves around one copy of the spheres (the 64-sphere target scene)
-  if (slots == 2 && !listed && 2 * stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3, 8) <= size_t(160 * 1024)) {
+  if (slots == 2 && !refr && !listed && 2 * stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr, 3, 8) <= size_t(160 * 1024)) {
     slots = 4;
     wg_waves = 8;
   }
@@ -3957,7 +3963,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         // (and never more than the LDS lets stay resident)
         // (many-sphere scenes: 1 = the list / grid kernel, 2 / 3 = its forms with eight / sixteen waves per workgroup)
         const int list_kernel = (p.grid_dim > 0 || p.list_dim > 0) ? (wg_waves == 16 ? 3 : wg_waves == 8 ? 2 : 1) : 0;
-        const unsigned per_cu = wg_waves > 4 ? workgroups_per_cu(lds, unsigned(16 / wg_waves)) : workgroups_per_cu(lds, slots == 2 ? 3u : unsigned(RT_WAVES_PER_SIMD));
+        const unsigned per_cu = wg_waves > 4 ? workgroups_per_cu(lds, unsigned(16 / wg_waves)) : workgroups_per_cu(lds, (slots == 2 && !refr) ? 3u : unsigned(RT_WAVES_PER_SIMD));
         const unsigned threads = unsigned(wg_waves) * 64u;
         const dim3 sgrid(std::min((grid.x + threads / 64 - 1) / (threads / 64), unsigned(ctx->n_cus) * per_cu), 1, 1);
         static_assert(sizeof(rt_camera) == 48, "the stream kernel copies cameras as 12 floats");

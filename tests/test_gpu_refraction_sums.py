@@ -115,3 +115,52 @@ def test_bright_lights_saturate_and_negative_colours_fall_back(renderer, oracle)
         o = oracle.render_scene(scene, 320, 180, samples=1, max_depth=5, mode="K", seed=2)
         check_rgb(img, o["rgb8"])
         assert img.max() == 255
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_samples_in_one_launch_on_refractive_scenes(renderer, oracle, name):
+    """2 .. 64 samples per pixel of a refractive scene are shaded by ONE stream-kernel launch, every sample's tree summed
+    into the tile's slot (render_pixel :292-297): byte-identical run to run and across row tiles, within the bar of the
+    oracle, and — mode C, a power of two of samples: every sample is the same tree — identical to the one-sample frame."""
+    import torch
+    from test_gpu_parity import check_rgb
+    scene = SCENES[name]()
+    renderer.upload_scene(scene)
+    w, h, D = 333, 187, 5
+    for spp in (2, 3, 8):
+        a = renderer.render(w, h, spp, max_depth=D, rng_mode="K", seed=6)
+        assert torch.equal(a, renderer.render(w, h, spp, max_depth=D, rng_mode="K", seed=6))
+        rows = renderer.render_rows(w, h, spp, tile_rows=8, tile_first=1, tile_stride=3, max_depth=D, rng_mode="K", seed=6)
+        assert torch.equal(rows, a[torch.from_numpy(tiling.local_rows(h, 8, 1, 3)).cuda()])
+        if spp <= 3:
+            o = oracle.render_scene(scene, w, h, samples=spp, max_depth=D, mode="K", seed=6)
+            check_rgb(a.cpu().numpy(), o["rgb8"])
+    one = renderer.render(w, h, 1, max_depth=D, rng_mode="C")
+    d = (one.to(torch.int16) - renderer.render(w, h, 4, max_depth=D, rng_mode="C").to(torch.int16)).abs()
+    assert int(d.max()) == 0          # (4 x the same integers, scaled by 2^-2: exact)
+    # the float-slab path (RT_OPT_TILE_FLUSH off) agrees up to the last bit of the sums
+    try:
+        renderer.set_tile_flush(False)
+        b = renderer.render(w, h, 3, max_depth=D, rng_mode="K", seed=6)
+    finally:
+        renderer.set_tile_flush(True)
+    d = (renderer.render(w, h, 3, max_depth=D, rng_mode="K", seed=6).to(torch.int16) - b.to(torch.int16)).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01
+
+
+def test_many_frames_at_64_samples_stay_within_the_record_budget(renderer):
+    """A batch whose tile records (144 B per tile, frame and sample) would exceed the launch's budget is split into several
+    launches instead of one allocation of hundreds of GB: 100 frames of 1080p at 64 samples per pixel; frames of both
+    launches equal their single renders."""
+    import torch
+    renderer.upload_scene(default_scene())
+    n = 100
+    cams = [orbit_camera(f, 128) for f in range(n)]
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    batch = renderer.render_frames(cams, list(range(n)), 1920, 1080, 64, max_depth=3, rng_mode="K")
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < (40 << 30)
+    for f in (0, 80, 81, 99):
+        assert torch.equal(batch[f], renderer.render(1920, 1080, 64, camera=cams[f], seed=f, max_depth=3, rng_mode="K"))
