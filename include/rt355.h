@@ -90,27 +90,24 @@ int rt_synchronize(rt_ctx* ctx);
  *   RT_OPT_OCCLUDER_TABLE: 1 (default) = the shadow scan of a hit on object k only looks at the spheres
  *   that can shadow some point of k (see rt_occluder_table); 0 = at every sphere, as the reference
  *   does.  Images are byte-identical either way (tests); takes effect at the next rt_upload_scene.
- *   RT_OPT_SPHERE_GRID: 1 (default) = reflection rays of scenes with >= 256 spheres (no cubes, no
- *   refraction) walk a uniform grid built at scene upload instead of testing every sphere; 0 = the
- *   plain scan of find_nearest_intersection (raytracer.py:152-172).  Same images (tests); takes effect
- *   at the next rt_upload_scene.
  *   RT_OPT_QUEUE_SPILL: 1 (default) = on refractive scenes a wave of the stream kernel whose work queue
  *   cannot take a full pass's children sets its 64 shallowest records aside in device memory (<= 32 blocks of
  *   3 KB per wave, allocated on first use) instead of shrinking the pass; 0 = shrink only; 2..32 = at most
- *   that many blocks per wave (tests: a wave whose stack is full shrinks its passes again).  Same images to
- *   float summation order (tests).
+ *   that many blocks per wave (tests: a wave whose stack is full shrinks its passes again).  Same bytes either
+ *   way (tests): the pixel sums are integers.
  *   RT_OPT_TILE_FLUSH: 1 (default) = the stream kernel stages the finished pixels of a tile in LDS and stores the
  *   tile whole (8 x 24 contiguous bytes, whole dwords) when its last pixel is in — the coalesced packed-RGB store
  *   of the frame (raytracer.py:318, :325); 0 = every finished pixel is stored by itself (three byte stores: one
- *   memory request per pixel).  Same bytes either way (tests).  Used for 8-bit frames at one sample per pixel of
- *   scenes without refraction; the other paths store as before.
- *   RT_OPT_REFLECT_TABLE: 1 (default) = reflection rays of sphere-only opaque scenes with 4 .. 255 spheres look
- *   only at the spheres a table built at scene upload lists for (object they leave, direction bucket) — see
- *   rt_reflect_table; 0 = the plain scan of find_nearest_intersection (raytracer.py:152-172).  Same images
- *   (tests); takes effect at the next rt_upload_scene. */
+ *   memory request per pixel).  Same bytes either way on opaque scenes (tests).  The tile slots also carry the
+ *   one-launch path for 2 .. 64 samples per pixel and the fixed-point pixel sums of refractive scenes (see
+ *   rt_set_refraction); with 0 those fall back to float sums in device memory.
+ *   RT_OPT_REFLECT_TABLE: 1 (default) = reflection (and refraction) rays of scenes with 4 or more spheres and no
+ *   cubes look only at the spheres a table built at scene upload lists for (object they leave, direction bucket) —
+ *   bit masks up to 255 spheres (see rt_reflect_table), lists from 256 on; 0 = the plain scan of
+ *   find_nearest_intersection (raytracer.py:152-172).  Same images (tests); takes effect at the next rt_upload_scene.
+ *   (Option 3, a uniform grid for those rays, was removed in round 3: the lists replaced it.) */
 #define RT_OPT_KERNEL 1
 #define RT_OPT_OCCLUDER_TABLE 2
-#define RT_OPT_SPHERE_GRID 3
 #define RT_OPT_QUEUE_SPILL 4
 #define RT_OPT_TILE_FLUSH 5
 #define RT_OPT_REFLECT_TABLE 6
@@ -129,9 +126,13 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
 /* Material.refraction / Material.refractive_index (raytracer.py:43, :213-230, :252-254) of the spheres
  * of the uploaded scene, n_spheres values each (host pointers).  rt_upload_scene resets them to
  * Material's defaults (0, 1); call this after it.  While any refraction is > 0 the renderer follows
- * both children of a hit, a shadow ray is blocked only by an opaque NEAREST hit (:187, :202), pixels
- * are summed with float atomics (run-to-run differences at FP32 rounding level), and
- * RT_KERNEL_PIXEL is refused. */
+ * both children of a hit, a shadow ray is blocked only by an opaque NEAREST hit (:187, :202), and
+ * RT_KERNEL_PIXEL is refused.  A pixel is then the sum over the nodes of a tree; 8-bit frames at up to 64 samples
+ * per pixel sum them in 32-bit fixed point (24 fractional bits, saturating at 256) per tile in LDS: the bytes of a
+ * frame do not depend on the run, the tiling or the batch.  Float output (rt_render_chunk), more than 64 samples,
+ * RT_OPT_TILE_FLUSH off, and scenes in which a node's share can be negative (a negative colour component, light
+ * colour, intensity, specular or reflection / refraction outside [0, 1]) are summed with float atomics in device
+ * memory instead: run-to-run differences at FP32 rounding level. */
 int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refractive_index, int n_spheres);
 
 /* Host-only helper (needs no GPU, no context): the occluder table rt_upload_scene builds for the shadow

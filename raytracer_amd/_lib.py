@@ -16,7 +16,6 @@ FRAMES_PER_LAUNCH = 1024   # RT_FRAMES_PER_LAUNCH of include/rt355.h
 TILE_ENTRY_BYTES = 196     # RT_TILE_ENTRY_BYTES
 RT_OPT_KERNEL, RT_KERNEL_STREAM, RT_KERNEL_PIXEL = 1, 0, 1
 RT_OPT_OCCLUDER_TABLE = 2
-RT_OPT_SPHERE_GRID = 3
 RT_OPT_QUEUE_SPILL = 4
 RT_OPT_TILE_FLUSH = 5
 RT_OPT_REFLECT_TABLE = 6

@@ -31,15 +31,6 @@
 
 #include "../../include/rt355.h"
 
-#ifndef RT_ACC_BITS
-#define RT_ACC_BITS 1     // shadow verdicts accumulated with sign-bit and/or (1) or min/max (0)
-#endif
-#ifndef RT_NEAR_SRC
-#define RT_NEAR_SRC 2     // reflection-ray scan reads spheres from: 0 LDS, 2 scalar loads
-#endif
-#ifndef RT_CULL
-#define RT_CULL 1         // shadow scan: per-lane cone culling of spheres (0 = every sphere for every lane)
-#endif
 #ifndef RT_CULL_STATS
 #define RT_CULL_STATS 0   // diagnostic build: candidate / drain-turn counts of the culled shadow scan (tools/stamps.py)
 #endif
@@ -49,28 +40,8 @@
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4   // __launch_bounds__ occupancy target: caps VGPRs at 512/4 = 128
 #endif
-#ifndef RT_SHADOW_CHEAP
-#define RT_SHADOW_CHEAP 1 // shadow scan: plain discriminant + exact fallback in the ambiguous band
-#endif
-#ifndef RT_CUBE_SHADOW_SAT
-#define RT_CUBE_SHADOW_SAT 1    // lighting(): shadow rays against boxes by the line / box separating-axis test (0: the slab test, cube_t)
-#endif
 #ifndef RT_CUBE_SHADOW_CULL
 #define RT_CUBE_SHADOW_CULL 1   // lighting(): per-lane candidate boxes for the shadow rays (0: all boxes, for fuzzing)
-#endif
-#ifndef RT_LIGHT_FAST
-#define RT_LIGHT_FAST 1   // lighting(), bit 0 (on): light positions relative to P formed once per point (+1.2 %); bit 1 (off: measured -3 %, the
-                          // kernel then spills 10 VGPRs around the shadow loops): mirrored view vector and sign-bit selects in the shading
-#endif
-#ifndef RT_INTAKE_FALLTHROUGH
-#define RT_INTAKE_FALLTHROUGH 1
-#endif
-#ifndef RT_SHADE_MASK
-#define RT_SHADE_MASK 0   // 1: light weights selected by sign-bit masks, no branch around the powers — 20 straight-line instructions per
-                          // ray instead of 22 + 6 scalar, no extra spill, and measured 2.7 % SLOWER on config 2 and the target
-#endif
-#ifndef RT_GEOM_SRC
-#define RT_GEOM_SRC 0     // shadow scan reads spheres from: 0 LDS, 1 LDS prefetched, 2 scalar loads
 #endif
 
 namespace {
@@ -142,12 +113,6 @@ struct RenderParams {
   // row k is the run of 4-index chunks occl_start[k] .. occl_start[k + 1] of occl_items (uint16, ascending, padded with 0xFFFF)
   const uint32_t* occl_start;
   const uint2* occl_items;
-  // uniform grid over the spheres for reflection rays of many-sphere scenes (grid_dim = 0: none)
-  const uint32_t* grid_start;   // [grid_dim^3 + 1] first entry of each cell in grid_items
-  const uint16_t* grid_items;   // sphere indices, ascending within a cell
-  const uint16_t* grid_big;     // spheres that span too many cells: always tested
-  int grid_dim, grid_n_big;
-  float grid_min[3], grid_inv_cell[3], grid_cell[3];
   // direction table for reflection rays (refl_dim = 0: none): [object][6 refl_dim^2 direction buckets][refl_pairs] 64-bit
   // masks of the spheres a ray that leaves the object in a direction of the bucket can hit (nearest_table)
   const uint2* refl_tab;
@@ -160,8 +125,6 @@ struct RenderParams {
   const float4* cubes;   // [n_cubes][2] min xyz -, max xyz - (raytracer.py:56-60); objects n_spheres.. of mat/spec/refr
   int n_cubes;           // > 0: the CUBES kernels run
   int defer_output;      // REFR path: pixels are resolved from `accum` after the last sample (rt_resolve_kernel)
-  int defer_sparse;      // ... and only for the tiles the visibility pass marked occupied (one sample per pixel, 8-bit frames): that
-                         // pass clears their pixel sums and writes the black of every other tile itself; rt_resolve_tiles_kernel
   int tile_flush;        // the stream kernel stores every occupied tile whole (its SLOTS variant): the visibility pass
                          // writes the pixels of empty tiles only
   long long vis_sample_stride;  // all samples shaded by one stream-kernel launch (the kernels' MULTI variants): elements
@@ -342,13 +305,12 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const
                                             int n, float ox, float oy, float oz, float dx, float dy,
                                             float dz, float& best_t, int& best_i) {
   // only the fused multiply-adds written out below: the hit distance must come out the same to the
-  // last bit wherever this test is inlined (sphere_t_exact, nearest_grid), whatever the optimiser
+  // last bit wherever this test is inlined (sphere_t_exact), whatever the optimiser
   // would contract in each context
 #pragma clang fp contract(off)
   const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // :95, computed, not assumed 1
   best_t = INFINITY;
   best_i = -1;
-#if RT_NEAR_SRC == 2
   // Scalar loads: four spheres per turn (64 B), the next four requested before these are tested, so the load's
   // latency passes under ~60 vector instructions instead of being waited for sphere by sphere.  The list is
   // padded with eight never-hit spheres (r^2 = -inf, rt_upload_scene), so neither the last block nor the
@@ -370,24 +332,6 @@ __device__ __forceinline__ void nearest_hit(const float4* __restrict__ sg, const
       const float4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
       n0 = src[i + 4]; n1 = src[i + 5]; n2 = src[i + 6]; n3 = src[i + 7];
       test(c0, i); test(c1, i + 1); test(c2, i + 2); test(c3, i + 3);
-    }
-    return;
-  }
-#endif
-  const float4* src = sg;   // wave-uniform address: LDS broadcast read
-#pragma unroll 4
-  for (int i = 0; i < n; ++i) {
-    const float4 s = src[i];
-    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-    const float q = fmaf(cz, dz, fmaf(cy, dy, cx * dx)) * inv_a;
-    const float lx = fmaf(-q, dx, cx), ly = fmaf(-q, dy, cy), lz = fmaf(-q, dz, cz);
-    const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, s.w)));  // r^2 - |l|^2
-    if (dl >= 0.0f) {
-      const float t = q - fsqrt(dl * inv_a);
-      if (t > 0.0f && t < best_t) {
-        best_t = t;
-        best_i = i;
-      }
     }
   }
 }
@@ -498,77 +442,6 @@ __device__ __forceinline__ void nearest_object(const float4* __restrict__ sg, co
   }
 }
 
-// find_nearest_intersection for scenes with many spheres: a uniform grid (built at scene upload) walked
-// per lane with a 3D-DDA.  Every sphere a cell lists is tested with the expressions of nearest_hit(); the
-// walk ends when the best hit lies before the exit of the current cell, or outside the grid.  Results equal
-// the plain scan's: the nearest sphere is listed in the cell that holds its hit point (cells list
-// spheres with 2 % of a cell of slack, far above the FP32 error of the walk), and ties go to the
-// lowest index explicitly, as cells are not visited in index order.  Spheres that span many cells
-// (`grid_big`) are tested up front.  Lanes walk different cells, so the wave loops until its last lane is done;
-// every turn a lane either tests one sphere or moves to the next cell.
-__device__ __forceinline__ void nearest_grid(const RenderParams& p, const float4* __restrict__ sg, float ox, float oy,
-                                             float oz, float dx, float dy, float dz, float& best_t, int& best_i) {
-  const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-  best_t = INFINITY;
-  best_i = -1;
-  auto test = [&](int j) {
-    float dl;
-    const float t = sphere_t_exact(sg[j], ox, oy, oz, dx, dy, dz, inv_a, dl);
-    if (dl >= 0.0f && t > 0.0f && (t < best_t || (t == best_t && j < best_i))) { best_t = t; best_i = j; }
-  };
-  for (int b = 0; b < p.grid_n_big; ++b) test(int(p.grid_big[b]));     // wave-uniform
-  const int G = p.grid_dim;
-  // reciprocal directions; a zero component becomes a huge finite slope (no 0 * inf below)
-  auto safe_inv = [](float d) { return 1.0f / (fabsf(d) < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d); };
-  const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-  const float ex = p.grid_cell[0] * float(G), ey = p.grid_cell[1] * float(G), ez = p.grid_cell[2] * float(G);
-  const float ax = (p.grid_min[0] - ox) * ix, bx = (p.grid_min[0] + ex - ox) * ix;
-  const float ay = (p.grid_min[1] - oy) * iy, by = (p.grid_min[1] + ey - oy) * iy;
-  const float az = (p.grid_min[2] - oz) * iz, bz = (p.grid_min[2] + ez - oz) * iz;
-  const float t0 = fmaxf(0.0f, fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz))));
-  const float t1 = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
-  bool active = t0 <= t1;                     // the ray touches the grid's box
-  const float sx0 = fmaf(dx, t0, ox), sy0 = fmaf(dy, t0, oy), sz0 = fmaf(dz, t0, oz);
-  int cx = min(G - 1, max(0, int((sx0 - p.grid_min[0]) * p.grid_inv_cell[0])));
-  int cy = min(G - 1, max(0, int((sy0 - p.grid_min[1]) * p.grid_inv_cell[1])));
-  int cz = min(G - 1, max(0, int((sz0 - p.grid_min[2]) * p.grid_inv_cell[2])));
-  const int stx = dx < 0.0f ? -1 : 1, sty = dy < 0.0f ? -1 : 1, stz = dz < 0.0f ? -1 : 1;
-  // ray parameter at which the walk leaves the current cell along each axis, and its step per cell
-  float tmx = (p.grid_min[0] + float(cx + (stx > 0 ? 1 : 0)) * p.grid_cell[0] - ox) * ix;
-  float tmy = (p.grid_min[1] + float(cy + (sty > 0 ? 1 : 0)) * p.grid_cell[1] - oy) * iy;
-  float tmz = (p.grid_min[2] + float(cz + (stz > 0 ? 1 : 0)) * p.grid_cell[2] - oz) * iz;
-  const float tdx = p.grid_cell[0] * fabsf(ix), tdy = p.grid_cell[1] * fabsf(iy), tdz = p.grid_cell[2] * fabsf(iz);
-  uint32_t cur = 0u, end = 0u;
-  if (active) {
-    const int cell = (cz * G + cy) * G + cx;
-    cur = p.grid_start[cell]; end = p.grid_start[cell + 1];
-  }
-  int guard = 3 * G + 8;                      // cells a walk can visit at most (a safety net: the walk ends by itself)
-  while (__ballot(active) != 0ull) {
-    if (active) {
-      if (cur < end) {
-        test(int(p.grid_items[cur]));
-        ++cur;
-      } else {
-        const float t_exit = fminf(tmx, fminf(tmy, tmz));
-        if (best_t <= t_exit || --guard < 0) {
-          active = false;                     // nothing nearer can follow
-        } else {
-          if (tmx <= tmy && tmx <= tmz) { cx += stx; tmx += tdx; }
-          else if (tmy <= tmz) { cy += sty; tmy += tdy; }
-          else { cz += stz; tmz += tdz; }
-          if (uint32_t(cx) >= uint32_t(G) || uint32_t(cy) >= uint32_t(G) || uint32_t(cz) >= uint32_t(G)) {
-            active = false;                   // left the grid
-          } else {
-            const int cell = (cz * G + cy) * G + cx;
-            cur = p.grid_start[cell]; end = p.grid_start[cell + 1];
-          }
-        }
-      }
-    }
-  }
-}
-
 // find_nearest_intersection for reflection rays of sphere-only opaque scenes with more than a handful of spheres:
 // a ray that leaves object k (origin within 0.001 of its surface) and hits sphere j points within
 // asin((r_k + r_j) / |J - K|) of the direction K -> J, whatever its origin — so which spheres a ray CAN hit
@@ -620,8 +493,7 @@ __device__ __forceinline__ void nearest_table(const RenderParams& p, const float
 
 // The same for scenes with 256 spheres or more, where a mask per entry would be mostly zeros: an entry is a short
 // list of sphere indices, stored in chunks of four (one 8-byte load; the next chunk is requested before this one is
-// tested).  Replaces the grid walk (nearest_grid, kept behind RT_OPT_REFLECT_TABLE = 0): no cell-to-cell stepping,
-// two dependent loads per ray instead of two per cell.
+// tested): two dependent loads per ray.
 __device__ __forceinline__ void nearest_list(const RenderParams& p, const float4* __restrict__ sg, int obj, float ox,
                                              float oy, float oz, float dx, float dy, float dz, float& best_t,
                                              int& best_i) {
@@ -956,7 +828,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
   const float vdn = -(fmaf(dz, nz, fmaf(dy, ny, dx * nx)));  // view . normal, view = -D (:257)
   float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
   float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
-#if RT_LIGHT_FAST
   // Per point, not per ray: the area light's corner seen from P — sample j is  A + u (r_u - 0.5) + v (r_v - 0.5) - P
   // = (A - P - 1.5 (u + v)) + u (1 + r_u) + v (1 + r_v), and the draws come as 1 + r — and the mirrored view vector:
   // view . (L - N (2 L.N))  (:192-193 / :207-208) = -(D - 2 (D.N) N) . L.
@@ -964,10 +835,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
   // another, and the stream and pixel kernels then differ in a last bit somewhere — found by tools/fuzz_culls.py)
   const float cax = fmaf(-1.5f, L.au[0] + L.av[0], L.apos[0] - px), cay = fmaf(-1.5f, L.au[1] + L.av[1], L.apos[1] - py),
               caz = fmaf(-1.5f, L.au[2] + L.av[2], L.apos[2] - pz);
-#endif
-#if RT_LIGHT_FAST & 2
-  const float nrx = -fmaf(2.0f * vdn, nx, dx), nry = -fmaf(2.0f * vdn, ny, dy), nrz = -fmaf(2.0f * vdn, nz, dz);
-#endif
   // Rays in several batches (REFR, scenes with boxes): the spheres 0..63 / boxes 0..31 that the FIRST batch's culls let through.  That
   // batch holds the point-light ray, so its survivors are a superset of every later batch's: the later batches test these
   // without culling again, and a ray that hits objects of BOTH kinds finds its nearest hit among them (no other object can
@@ -983,7 +850,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     for (int k = 0; k < B; ++k) {
       const int j = base + k;
       float lx, ly, lz;
-#if RT_LIGHT_FAST & 1
       if (j == 0) {  // scene['global_light'] (:198)
         lx = L.ppos[0] - px; ly = L.ppos[1] - py; lz = L.ppos[2] - pz;
       } else {       // area-light sample j-1 (:180-183)
@@ -993,19 +859,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         ly = fmaf(L.av[1], rv1, fmaf(L.au[1], ru1, cay));
         lz = fmaf(L.av[2], rv1, fmaf(L.au[2], ru1, caz));
       }
-#else
-      if (j == 0) {  // scene['global_light'] (:198)
-        lx = L.ppos[0]; ly = L.ppos[1]; lz = L.ppos[2];
-      } else {       // area-light sample j-1 (:180-182)
-        float ru1, rv1;
-        draw_pair1<MODE>(level_key, uint32_t(j - 1), ru1, rv1);
-        const float ru = ru1 - 1.5f, rv = rv1 - 1.5f;                 // random.random() - 0.5
-        lx = fmaf(L.av[0], rv, fmaf(L.au[0], ru, L.apos[0]));
-        ly = fmaf(L.av[1], rv, fmaf(L.au[1], ru, L.apos[1]));
-        lz = fmaf(L.av[2], rv, fmaf(L.au[2], ru, L.apos[2]));
-      }
-      lx -= px; ly -= py; lz -= pz;                        // :183 / :198
-#endif
       // a ray beyond the light's sample count gets L = 0: it can never be shadowed and every
       // weight below (N.L, V.R) is then 0 too
       const float inv = (j < nrays) ? frsq(fmaf(lz, lz, fmaf(ly, ly, lx * lx))) : 0.0f;
@@ -1021,7 +874,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     auto test_sphere = [&](const float4 g, uint32_t glass = 0u) {
       const float cx = g.x - sx, cy = g.y - sy, cz = g.z - sz;
       const float c = fmaf(cz, cz, fmaf(cy, cy, fmaf(cx, cx, -g.w)));
-#if RT_SHADOW_CHEAP
       // Two-tier test.  Tier 1 is the plain discriminant nb^2 - c (4 ops per ray): its FP32 error is
       // below 2^-20 |co|^2 (3 roundings in nb, 3 in c, |L|^2 = 1 +- 4 ulp), so with thr = 2^-18 |co|^2
       //   dh = nb^2 - (c + thr) >= 0  is a certain hit, and  dh + 2 thr < 0  a certain miss.
@@ -1044,7 +896,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         asm volatile("" : "+v"(m[k]), "+v"(amb));   // keep both chains sequential (no reassociation tree)
       }
       if (int(amb) < 0)
-#endif
       {
         const float r2 = (c > 0.0f) ? g.w : -INFINITY;
 #pragma unroll
@@ -1052,18 +903,13 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
           const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
           const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
           const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
-#if RT_ACC_BITS
           const uint32_t verdict = __float_as_uint(dl) | __float_as_uint(nb);
           m[k] = __uint_as_float(__float_as_uint(m[k]) & (REFR ? verdict | glass : verdict));
           if constexpr (REFR) mrf[k] = __uint_as_float(__float_as_uint(mrf[k]) & (verdict | (glass ^ 0x80000000u)));
           asm volatile("" : "+v"(m[k]));   // keep the and-chain sequential (no reassociation tree)
-#else
-          m[k] = __builtin_fmaxf(m[k], __builtin_fminf(dl, nb));
-#endif
         }
       }
     };
-#if RT_CULL
     // Per-lane sphere culling.  The B rays of a lane leave one point towards one small light, so
     // almost every sphere is far from all of them; but lanes of a wave are unrelated pixels, so no
     // sphere can be skipped for the whole wave.  Instead each lane first collects, 32 spheres at
@@ -1196,39 +1042,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
         }
       }
     }
-#elif RT_GEOM_SRC == 1
-    // LDS broadcast reads, software-pipelined one pair of spheres ahead so the ds_read latency is
-    // covered by the previous pair's 26 ray tests
-    {
-      float4 g0 = sg[0], g1 = sg[n > 1 ? 1 : 0];
-      int i = 0;
-      for (; i + 2 < n; i += 2) {
-        const float4 h0 = sg[i + 2], h1 = sg[i + 3 < n ? i + 3 : i + 2];
-        test_sphere(g0);
-        test_sphere(g1);
-        g0 = h0; g1 = h1;
-      }
-      if (i < n) test_sphere(g0);
-      if (i + 1 < n) test_sphere(g1);
-    }
-#elif RT_GEOM_SRC == 2
-    // wave-uniform scalar loads straight from the (constant, L2/K$-resident) geometry buffer: the
-    // sphere lives in SGPRs, no LDS traffic and no VGPRs for it
-    // (software-pipelined one sphere ahead: the next s_load_dwordx4 is in flight during this
-    // sphere's 13 ray tests, and costs SGPRs only)
-    if (n > 0) {
-      cgeom_t cg = as_const(gg);
-      float4 cur = cg[0];
-      for (int i = 0; i < n; ++i) {
-        const float4 nxt = cg[i + 1 < n ? i + 1 : i];
-        test_sphere(cur);
-        cur = nxt;
-      }
-    }
-#else
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) test_sphere(sg[i]);
-#endif
     if constexpr (CUBES) {
       // any-hit over the cubes: the ray is blocked if intersect_cube gives a non-zero t of EITHER sign
       // (:137, :162 — see cube_t): the ray's LINE decides.  Per lane, the cubes whose bounding sphere reaches into the
@@ -1276,7 +1089,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
             bool glass_cube = false;
             if constexpr (REFR) glass_cube = refr[n + c].x > 0.0f;
             (void)glass_cube;
-#if RT_CUBE_SHADOW_SAT
             // A shadow ray is blocked by a box iff its LINE meets the box (cube_t accepts either sign of t; t = 0 exactly —
             // the origin in an exit plane — has measure zero).  Line against box by the three separating axes d x e_i:
             //   |(d x m)_i| <= h_j |d_k| + h_k |d_j|,  m = S - centre, h = half extents
@@ -1298,22 +1110,6 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
                 }
               }
             }
-#else
-#pragma unroll
-            for (int k = 0; k < B; ++k) {
-              float t;
-              int face;
-              float lx = Lx[k], ly = Ly[k], lz = Lz[k];
-              asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz));     // keeps the 39 reciprocals inside the loop (registers)
-              if (cube_t(lo, hi, sx, sy, sz, lx, ly, lz, frcp(lx), frcp(ly), frcp(lz), t, face)) {
-                if constexpr (REFR) {                              // (which kind of hit: see below)
-                  if (glass_cube) mrf[k] = 0.0f; else m[k] = 0.0f;
-                } else {
-                  m[k] = 0.0f;
-                }
-              }
-            }
-#endif
           }
         }
       }
@@ -1379,38 +1175,13 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     }
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-#if RT_LIGHT_FAST & 2
-      // (one ray after the other — this ray's direction passes through the same statement as the sums of the rays before
-      // it: interleaved, the 13 power chains take registers that the kernel does not have)
-      asm volatile("" : "+v"(Lx[k]), "+v"(ad), "+v"(as));
-#endif
       const float ndl = fmaf(nz, Lz[k], fmaf(ny, Ly[k], nx * Lx[k]));
-#if RT_LIGHT_FAST & 2
-      // max(0, x) of a lit ray, 0 of a shadowed one, by sign bits (three full-rate ops; v_max and v_cndmask are
-      // half rate, and a select would bring a branch around the powers): x is kept iff neither x nor ~m is negative
-      const float vr = fmaf(nrz, Lz[k], fmaf(nry, Ly[k], nrx * Lx[k]));
-      const uint32_t shadowed = ~__float_as_uint(m[k]);                                   // sign set: blocked (:187 / :202)
-      auto lit_max0 = [&](float x) {
-        return __uint_as_float(__float_as_uint(x) & ~uint32_t(int32_t(__float_as_uint(x) | shadowed) >> 31));
-      };
-      const float wd = lit_max0(ndl);                                // :188 / :203
-      const float ws = pow50(lit_max0(vr));                          // :193 / :208  (0 ** 50 = 0)
-#else
       // view . (L - N*(2 L.N))  (:192-193 / :207-208; the sign of R is the reference's)
       const float vdl = -(fmaf(dz, Lz[k], fmaf(dy, Ly[k], dx * Lx[k])));
       const float vr = fmaf(-2.0f * ndl, vdn, vdl);
       const bool lit = int(__float_as_uint(m[k])) < 0;               // :187 / :202
-#if RT_SHADE_MASK
-      // (lit or not by the verdict's sign bit as a mask: no select, no branch around the seven multiplies)
-      const uint32_t litmask = uint32_t(int32_t(__float_as_uint(m[k])) >> 31);
-      const float wd = __uint_as_float(__float_as_uint(max0(ndl)) & litmask);              // :188 / :203
-      const float ws = __uint_as_float(__float_as_uint(pow50(max0(vr))) & litmask);        // :193 / :208
-      (void)lit;
-#else
       const float wd = lit ? max0(ndl) : 0.f;                        // :188 / :203
       const float ws = lit ? pow50(max0(vr)) : 0.f;                  // :193 / :208
-#endif
-#endif
       if (k == 0) {
         if (base == 0) { pd = wd; ps = ws; } else { ad += wd; as += ws; }
       } else { ad += wd; as += ws; }
@@ -1419,12 +1190,8 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if RT_CULL_STATS
   dbg_flush(dbg_rel_, dbg_lanes_, dbg_iters_, dbg_turns_);
 #endif
-#if RT_LIGHT_FAST & 2
-  return LightSums{pd, ps, ad, as, -nrx, -nry, -nrz};
-#else
   const float dn2 = 2.0f * fmaf(dz, nz, fmaf(dy, ny, dx * nx));
   return LightSums{pd, ps, ad, as, fmaf(-dn2, nx, dx), fmaf(-dn2, ny, dy), fmaf(-dn2, nz, dz)};
-#endif
 }
 
 // One shaded hit (trace_ray :240-258 without the recursion): hit point P on sphere `idx`, incoming
@@ -1522,13 +1289,7 @@ __device__ __forceinline__ void finish_pixel(const RenderParams& p, long long gp
     *stage_slot = rgbx;
   } else if (p.out_rgb) {   // stream kernel: only hit pixels end here, scattered over the frame
     uint8_t* o = p.out_rgb + gpix * 3;
-#if defined(RT_EXP_STORE32)
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(o) & ~uintptr_t(3)) = rgbx;   // timing experiment only
-#elif defined(RT_EXP_NOSTORE)
-    if (rgbx == 0x12345678u) o[0] = 1;
-#else
     o[0] = uint8_t(rgbx); o[1] = uint8_t(rgbx >> 8); o[2] = uint8_t(rgbx >> 16);
-#endif
   }
 }
 
@@ -1676,7 +1437,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
   // The common case: a whole block of an 8-bit frame with dword-aligned rows, one sample per pixel, nothing else
   // asked for.  Every pixel this kernel writes is then black (misses are final, hits get a placeholder), which
   // the short forms of the epilogue below rely on.
-  const bool simple = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && (!p.defer_output || p.defer_sparse) && p.out_rgb && rows == 8 &&
+  const bool simple = !MULTI && p.n_samples == 1 && !p.out_f32 && !p.out_hit && !p.defer_output && p.out_rgb && rows == 8 &&
                       cols[NT - 1] == 8 && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
                       (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
   // The wave culls the spheres against the bounding cone of its rays first (primary_hit_culled): with many
@@ -1720,9 +1481,6 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
     }
     // a block that no sphere reaches builds no rays: all its pixels miss (with more than 64 spheres the later
     // chunks are not looked at here, and with cubes every ray is needed for them)
-    #if defined(RT_EXP_VIS_NORAYS)
-    const bool need_rays = false;   // timing experiment only: the pass's floor (cone, cull, black pixels)
-#else
     bool cube_reach = false;
     if constexpr (CUBES) {   // (one cube per lane; beyond 64 cubes, or without a cone — no spheres at all —, every ray is built)
       cube_reach = true;
@@ -1733,10 +1491,9 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
       }
     }
     const bool need_rays = !RT_VIS_SKIP || cube_reach || reached != 0ull || (p.n_spheres > 64 && !region_kept);
-#endif
     // (nothing to write at all: a sample before the last of the MULTI path leaves only records and `present` bits
     // of tiles it hit; on the deferred-output path — refractive scenes — every pixel comes from rt_resolve_kernel)
-    if (!need_rays && !p.out_hit && (MULTI ? !last_sample : (p.defer_output != 0 && !p.defer_sparse))) return;
+    if (!need_rays && !p.out_hit && (MULTI ? !last_sample : p.defer_output != 0)) return;
     if constexpr (!MULTI) {
       // The common case of such a block — whole, one sample per pixel, 8-bit frame only, dword-aligned rows —
       // leaves at once: its rows are NT x 24 contiguous bytes of black, 12 per lane with NT = 4 (one store
@@ -1806,11 +1563,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
               atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));
             }
           }
-          if (occupied && p.defer_sparse) {   // the tile's pixel sums start at zero (the stream kernel adds tree nodes into them)
-            float* a = p.accum + (accum_px + wpix0 + 8 * q) * 3;
-            a[0] = 0.f; a[1] = 0.f; a[2] = 0.f;
-          }
-          if (!(occupied && (p.tile_flush || p.defer_sparse)) && lane < 48) *reinterpret_cast<uint32_t*>(o + q * 24) = 0u;
+          if (!(occupied && p.tile_flush) && lane < 48) *reinterpret_cast<uint32_t*>(o + q * 24) = 0u;
         }
         return;
       }
@@ -1829,7 +1582,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
   // ... and a header names the tile, so a record is self-describing for whoever loads it
   int16_t* rec = p.vis + (size_t)frame * p.vis_stride + ((size_t)(row0 >> 3) * p.tile_pitch + (col0 >> 3)) * kVisTile;
   uint8_t* out = p.out_rgb + frame_px * 3;
-  const bool write_rgb = p.out_rgb && last_sample && (!p.defer_output || p.defer_sparse);
+  const bool write_rgb = p.out_rgb && last_sample && !p.defer_output;
   const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
   const uint32_t id0 = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
                        uint32_t(col0 >> 3);               // tile id of the wave's first tile; the others follow
@@ -1879,12 +1632,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
       atomicOr(p.occ + size_t(h) * size_t(p.occ_words) + (slot >> 5), 1u << (slot & 31u));   // no return value: fire and forget
     }
     // (tile_flush: the stream kernel stores an occupied tile whole, its black pixels included)
-    if constexpr (!MULTI)
-      if (occupied && p.defer_sparse && live[q]) {
-        float* a = p.accum + (accum_px + wpix0 + 8 * q) * 3;
-        a[0] = 0.f; a[1] = 0.f; a[2] = 0.f;
-      }
-    if (write_rgb && !(occupied && (p.tile_flush || p.defer_sparse)))
+    if (write_rgb && !(occupied && p.tile_flush))
       store_tile8(out, p.nx, row0, col0 + 8 * q, rows, cols[q], lane, rgbx[q], dwords);
   }
 }
@@ -1922,10 +1670,10 @@ __global__ __launch_bounds__(RT_VIS_BLOCK, RT_VIS_WAVES) void rt_visibility_kern
   if constexpr (RT_VIS_SKIP && kVisRows > 1) {
     const long long frame_px = (long long)frame * p.frame_stride_px;
     const bool whole = rowR + 8 * kVisRows <= p.n_rows && p.nx - col0 >= 8 * NT;
-    const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : (p.defer_output != 0 && !p.defer_sparse));
+    const bool nothing_owed = !p.out_hit && (MULTI ? p.sample_index + 1 != p.n_samples : p.defer_output != 0);
     // (MULTI: the launch of the last sample writes the black of tiles that NO sample hit — `present` knows)
     const bool black_owed = (MULTI ? p.sample_index + 1 == p.n_samples : p.n_samples == 1) && !p.out_f32 && !p.out_hit &&
-                            (!p.defer_output || p.defer_sparse) && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
+                            !p.defer_output && p.out_rgb && whole && (p.nx & 3) == 0 && (frame_px & 3) == 0 &&
                             (reinterpret_cast<uintptr_t>(p.out_rgb) & 3) == 0;
     if constexpr (MANY) {
       {                         // many spheres: every chunk of 64 against the region's cone, the ballots kept for the blocks
@@ -2570,9 +2318,6 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
       }
       wave_lds_fence();
       st_fetch += RT_NOW() - s0;
-#if !RT_INTAKE_FALLTHROUGH
-      continue;
-#endif
       // (straight on into the pass: the intake ends only with a pass's worth of records, without a free slot, or with
       // nothing left anywhere — going round the loop first came to the same decisions through ~130 instructions of
       // scalar-register spill traffic at the loop head)
@@ -2852,7 +2597,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
           ++n_trace;
           if constexpr (GRID != 0) {
             if (p.list_dim > 0) nearest_list(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2);
-            else nearest_grid(p, sg, ox, oy, oz, dx, dy, dz, t, idx2);
+            else nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);   // (RT_OPT_REFLECT_TABLE off, or lists beyond 256 MB)
             face = 0;
           }
           else if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2); face = 0; }
@@ -3212,49 +2957,6 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(const RenderParams p) {
   }
 }
 
-// The same for the tiles the visibility pass marked occupied only (RenderParams::defer_sparse: refractive scenes at one
-// sample per pixel, 8-bit frames): every other tile is black already, and only these tiles' sums were ever cleared or
-// added to — on a mostly empty frame a fifth of the 12 + 3 bytes per pixel that clearing and resolving everything moves.
-// One wave per region of the visibility pass (kVisRows blocks of four tiles): lane t looks up the occupancy bit of tile
-// t, one ballot says which tiles there are, and the wave walks those — an empty region costs one load and one ballot
-// (with a wave per block and a dependent load per tile the kernel took 3.2 ms per 1024 frames of refractive_scene()).
-// Whole tiles leave as dwords (store_tile8).
-__global__ __launch_bounds__(128) void rt_resolve_tiles_kernel(const RenderParams p) {
-  constexpr int NT = kVisTiles, R = kVisRows;
-  static_assert(NT == 4 && NT * R <= 64, "lane t: tile t % 4 of block t / 4");
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * 2 + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * R);
-  if (p.nx - col0 <= 0) return;
-  const int lx = lane & 7, ly = lane >> 3;
-  const long long frame_px = (long long)frame * p.frame_stride_px, accum_px = (long long)frame * p.accum_stride_px;
-  uint8_t* out = p.out_rgb + frame_px * 3;
-  const bool dwords = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
-  bool there = false;
-  {
-    const int q = lane & 3, row0 = rowR + 8 * (lane >> 2);
-    if (lane < NT * R && row0 < p.n_rows && p.nx - col0 - 8 * q > 0) {
-      const uint32_t id = uint32_t(frame) * uint32_t(p.tile_pitch * p.tiles8_y) + uint32_t(row0 >> 3) * uint32_t(p.tile_pitch) +
-                          uint32_t(col0 >> 3) + uint32_t(q);
-      const uint32_t slot = id / kTileCounters, h = id % kTileCounters;
-      there = (p.occ[size_t(h) * size_t(p.occ_words) + (slot >> 5)] >> (slot & 31u)) & 1u;
-    }
-  }
-  unsigned long long todo = __ballot(there);
-  while (todo != 0ull) {
-    const int t = __ffsll((long long)todo) - 1;
-    todo &= todo - 1ull;
-    const int q = t & 3, row0 = rowR + 8 * (t >> 2);
-    const int rows = min(8, p.n_rows - row0), cols = min(8, p.nx - col0 - 8 * q);
-    uint32_t rgbx = 0u;
-    if (lx < cols && ly < rows) {
-      const float* a = p.accum + (accum_px + (long long)(row0 + ly) * p.nx + (col0 + 8 * q + lx)) * 3;
-      rgbx = pack_rgbx(a[0] * p.inv_samples, a[1] * p.inv_samples, a[2] * p.inv_samples);
-    }
-    store_tile8(out, p.nx, row0, col0 + 8 * q, rows, cols, lane, rgbx, dwords);
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side: context + C ABI
 // ------------------------------------------------------------------------------------------
@@ -3274,11 +2976,6 @@ struct rt_ctx {
   // their refraction values / the cubes)
   bool nonneg_scene = true, nonneg_refr = true, nonneg_cubes = true;
   bool sums_never_negative() const { return nonneg_scene && nonneg_refr && nonneg_cubes; }
-  uint32_t* d_grid_start = nullptr;   // sphere grid of many-sphere scenes (build_sphere_grid)
-  uint16_t* d_grid_items = nullptr;
-  uint16_t* d_grid_big = nullptr;
-  int grid_dim = 0, grid_n_big = 0;
-  float grid_min[3] = {0, 0, 0}, grid_inv_cell[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0};
   uint2* d_refl_tab = nullptr;        // direction table of reflection rays (build_reflect_table; grown on demand)
   size_t refl_tab_bytes = 0;
   int refl_dim = 0, refl_pairs = 0;
@@ -3290,7 +2987,6 @@ struct rt_ctx {
   size_t list_start_bytes = 0, list_items_bytes = 0;
   int list_dim = 0;
   bool reflect_table = true;          // RT_OPT_REFLECT_TABLE
-  bool sphere_grid = true;            // RT_OPT_SPHERE_GRID
   int queue_spill = 1;                // RT_OPT_QUEUE_SPILL: 0 off, 1 automatic depth, 2.. = at most that many blocks per wave
   uint32_t* d_glass_bits = nullptr;   // bit c: sphere c has refraction > 0 (rt_set_refraction; zero after rt_upload_scene)
   uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
@@ -3370,73 +3066,7 @@ struct Window {
   int x0, nx, n_rows, tile_rows, tile_first, tile_stride, y0;
 };
 
-// Uniform grid for nearest_grid(): G^3 cells over the bounding box of the spheres, G ~ cbrt(4 n).  A cell
-// lists every sphere whose bounding box, grown by 2 % of a cell, touches it (ascending indices); spheres
-// that would be listed in more than kGridMaxCellsPerSphere cells go to `big` instead.
-constexpr int kGridFrom = 256;                 // scenes with at least this many spheres get a grid (measured crossover: ~230)
-constexpr int kGridMaxDim = 32;
-constexpr int kGridMaxCellsPerSphere = 64;
-struct SphereGrid {
-  int dim = 0;
-  float mn[3], inv_cell[3], cell[3];
-  std::vector<uint32_t> start;
-  std::vector<uint16_t> items, big;
-};
-void build_sphere_grid(const float* geom4, int n, SphereGrid& g) {
-  g = SphereGrid();
-  if (n < kGridFrom) return;
-  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  for (int i = 0; i < n; ++i) {
-    const double r = std::sqrt(double(geom4[4 * i + 3]));
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = std::min(lo[k], double(geom4[4 * i + k]) - r);
-      hi[k] = std::max(hi[k], double(geom4[4 * i + k]) + r);
-    }
-  }
-  // 8 cells per sphere (1 ... 32 measured within 15 % of each other on config 4; the cell table in LDS
-  // instead of global memory is no faster and costs occupancy; separate walk / test loops are slower)
-  const int G = std::max(4, std::min(kGridMaxDim, int(std::cbrt(8.0 * n) + 0.5)));
-  double cell[3];
-  for (int k = 0; k < 3; ++k) {
-    const double pad = 1e-3 * (hi[k] - lo[k]) + 1e-3;
-    lo[k] -= pad; hi[k] += pad;
-    cell[k] = (hi[k] - lo[k]) / G;
-    g.mn[k] = float(lo[k]); g.cell[k] = float(cell[k]); g.inv_cell[k] = float(1.0 / cell[k]);
-  }
-  auto range = [&](int i, int k, int& a, int& b) {
-    const double r = std::sqrt(double(geom4[4 * i + 3])) * 1.0001 + 0.02 * cell[k];
-    a = std::max(0, std::min(G - 1, int(std::floor((double(geom4[4 * i + k]) - r - lo[k]) / cell[k]))));
-    b = std::max(0, std::min(G - 1, int(std::floor((double(geom4[4 * i + k]) + r - lo[k]) / cell[k]))));
-  };
-  std::vector<uint32_t> count(size_t(G) * G * G + 1, 0u);
-  std::vector<char> is_big(size_t(n), 0);
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int i = 0; i < n; ++i) {
-      int a[3], b[3];
-      for (int k = 0; k < 3; ++k) range(i, k, a[k], b[k]);
-      if (pass == 0) {
-        const long long cells = (long long)(b[0] - a[0] + 1) * (b[1] - a[1] + 1) * (b[2] - a[2] + 1);
-        if (cells > kGridMaxCellsPerSphere) { is_big[size_t(i)] = 1; g.big.push_back(uint16_t(i)); continue; }
-      } else if (is_big[size_t(i)]) {
-        continue;
-      }
-      for (int z = a[2]; z <= b[2]; ++z)
-        for (int y = a[1]; y <= b[1]; ++y)
-          for (int x = a[0]; x <= b[0]; ++x) {
-            const size_t c = (size_t(z) * G + y) * G + x;
-            if (pass == 0) ++count[c + 1];
-            else g.items[count[c]++] = uint16_t(i);
-          }
-    }
-    if (pass == 0) {
-      for (size_t c = 1; c < count.size(); ++c) count[c] += count[c - 1];
-      g.start = count;                         // start[c] = first entry of cell c, start[G^3] = entries
-      g.items.assign(size_t(count.back()), 0);
-    }
-  }
-  g.dim = G;
-}
-
+constexpr int kGridFrom = 256;   // scenes with at least this many spheres: shadow candidates and direction-table entries as LISTS (the list kernels)
 // Direction table for nearest_table(): bit j of entry [k][bucket] says that SOME ray which starts within rho_k =
 // r_k + 0.001 (+ margin) of K and whose direction lies in the bucket can hit sphere j.  Such a ray reaches a point
 // X of sphere j from an origin O:  X - O = (J - K) + e  with |e| <= rho_k + r_j, so its direction is within
@@ -3528,7 +3158,7 @@ void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& t
 }
 // The table as lists (nearest_list): start[k * nb + b] .. start[k * nb + b + 1] are the 4-index chunks of entry
 // [k][b] in `items` (ascending sphere indices, the last chunk padded with 0xFFFF).  Objects are independent, so the
-// build runs on several threads.  Returns false — no table, the grid walk stays — if the lists would exceed
+// build runs on several threads.  Returns false — no table, reflection rays scan every sphere — if the lists would exceed
 // kReflListMaxChunks (a scene where most spheres reach most directions of most objects: huge or interlocked spheres).
 constexpr int kReflListDim = RT_REFL_LIST_DIM;
 constexpr size_t kReflListMaxChunks = size_t(32) << 20;   // 256 MB of indices
@@ -3778,7 +3408,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   // all samples in one launch: the variant with three slots per wave where that buys a fourth workgroup per CU (scenes of
   // up to 36 spheres: config 2 at 2 / 4 samples 513 -> 545 / 531 -> 568 Grays/s; on larger scenes, where three workgroups
   // fit either way, it measured 9 % slower)
-  const bool listed = ctx->grid_dim > 0 || ctx->list_dim > 0;
+  const bool listed = ctx->n_spheres >= kGridFrom && !refr && !cubes && stream_kernel;   // the list kernels (lighting<LIST>, nearest_list)
   // Many spheres (the list / grid kernels): every workgroup holds a copy of the sphere list, 16 KB at 1024 spheres, so only
   // three workgroups of four waves fit a CU.  Workgroups of EIGHT waves share one copy: two of them (80 KB each at 1024
   // spheres) are 16 waves per CU.  Taken where that is more waves than the four-wave form holds, if need be without
@@ -3832,18 +3462,11 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32;
   p.occl_start = ctx->d_occl_start; p.occl_items = ctx->d_occl_items;
   p.glass_bits = ctx->d_glass_bits;
-  p.grid_start = ctx->d_grid_start; p.grid_items = ctx->d_grid_items; p.grid_big = ctx->d_grid_big;
-  p.grid_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->grid_dim;
   p.list_start = ctx->d_list_start; p.list_items = ctx->d_list_items;
   p.list_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->list_dim;
   p.refl_tab = ctx->d_refl_tab; p.refl_pairs = ctx->refl_pairs;
-  p.refl_dim = (cubes || !stream_kernel || p.grid_dim > 0 || p.list_dim > 0) ? 0 : ctx->refl_dim;
-  p.grid_n_big = ctx->grid_n_big;
-  for (int k = 0; k < 3; ++k) {
-    p.grid_min[k] = ctx->grid_min[k]; p.grid_inv_cell[k] = ctx->grid_inv_cell[k]; p.grid_cell[k] = ctx->grid_cell[k];
-  }
+  p.refl_dim = (cubes || !stream_kernel || listed) ? 0 : ctx->refl_dim;
   p.defer_output = (refr && !refr_slots) ? 1 : 0;
-  p.defer_sparse = (refr && !refr_slots && stream_kernel && samples == 1 && out_rgb && !out_f32) ? 1 : 0;
   p.tile_flush = slots ? 1 : 0;
   p.accum = ctx->d_accum;
   p.spill = ctx->d_spill; p.spill_blocks = spill_blocks;
@@ -3948,8 +3571,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         RT_HIP(ctx, hipGetLastError());
       }
     }
-    if (p.defer_output && !p.defer_sparse)   // every node of every sample adds into the pixel sums (defer_sparse: the visibility pass
-      RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));   // clears those of occupied tiles)
+    if (p.defer_output)   // every node of every sample adds into the pixel sums
+      RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, size_t(win_px) * 3 * size_t(nf) * sizeof(float), ctx->stream));
     if (multi)   // which samples of a tile hit anything: collected by the visibility launches below
       RT_HIP(ctx, hipMemsetAsync(ctx->d_present, 0, (size_t(frame_tiles) * size_t(nf) + 8) * sizeof(unsigned long long), ctx->stream));
     for (int s = 0; s < samples; ++s) {
@@ -3962,7 +3585,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
         // persistent stream kernel: as many workgroups as stay resident (4 per CU), never more than chunks
         // (and never more than the LDS lets stay resident)
         // (many-sphere scenes: 1 = the list / grid kernel, 2 / 3 = its forms with eight / sixteen waves per workgroup)
-        const int list_kernel = (p.grid_dim > 0 || p.list_dim > 0) ? (wg_waves == 16 ? 3 : wg_waves == 8 ? 2 : 1) : 0;
+        const int list_kernel = listed ? (wg_waves == 16 ? 3 : wg_waves == 8 ? 2 : 1) : 0;
         const unsigned per_cu = wg_waves > 4 ? workgroups_per_cu(lds, unsigned(16 / wg_waves)) : workgroups_per_cu(lds, (slots == 2 && !refr) ? 3u : unsigned(RT_WAVES_PER_SIMD));
         const unsigned threads = unsigned(wg_waves) * 64u;
         const dim3 sgrid(std::min((grid.x + threads / 64 - 1) / (threads / 64), unsigned(ctx->n_cus) * per_cu), 1, 1);
@@ -3978,12 +3601,7 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
           hipLaunchKernelGGL(shade, sgrid, dim3(threads), lds, ctx->stream, p);
         }
         if (p.defer_output && s + 1 == samples) {   // (never MULTI)
-          if (p.defer_sparse)
-            hipLaunchKernelGGL(rt_resolve_tiles_kernel, dim3(unsigned((w.n_rows + 8 * kVisRows - 1) / (8 * kVisRows)), unsigned((w.nx + 16 * kVisTiles - 1) / (16 * kVisTiles)), unsigned(nf)),
-                               dim3(128), 0, ctx->stream, p);
-          else
-            hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0,
-                               ctx->stream, p);
+          hipLaunchKernelGGL(rt_resolve_kernel, dim3(unsigned((win_px + 255) / 256), unsigned(nf), 1), dim3(256), 0, ctx->stream, p);
         }
       } else {
         if (rng_mode == RT_RNG_KEYED)
@@ -4055,10 +3673,6 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_refr, sizeof(float2) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_grid_start, sizeof(uint32_t) * (kGridMaxDim * kGridMaxDim * kGridMaxDim + 1))) != hipSuccess ||
-      (e = hipMalloc(&ctx->d_grid_items, sizeof(uint16_t) * size_t(kGridMaxCellsPerSphere) * RT_MAX_SPHERES)) != hipSuccess ||
-      (e = hipMalloc(&ctx->d_grid_big, sizeof(uint16_t) * RT_MAX_SPHERES)) != hipSuccess)
-    return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
     return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_occl_start, sizeof(uint32_t) * (RT_MAX_SPHERES + 1))) != hipSuccess) return bail(e, "hipMalloc");
@@ -4099,9 +3713,6 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_occl_items) (void)hipFree(ctx->d_occl_items);
   if (ctx->d_list_start) (void)hipFree(ctx->d_list_start);
   if (ctx->d_list_items) (void)hipFree(ctx->d_list_items);
-  if (ctx->d_grid_start) (void)hipFree(ctx->d_grid_start);
-  if (ctx->d_grid_items) (void)hipFree(ctx->d_grid_items);
-  if (ctx->d_grid_big) (void)hipFree(ctx->d_grid_big);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -4125,10 +3736,6 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (option == RT_OPT_KERNEL && (value == RT_KERNEL_STREAM || value == RT_KERNEL_PIXEL)) {
     ctx->kernel = value;
-    return RT_OK;
-  }
-  if (option == RT_OPT_SPHERE_GRID && (value == 0 || value == 1)) {
-    ctx->sphere_grid = value != 0;      // takes effect at the next rt_upload_scene
     return RT_OK;
   }
   if (option == RT_OPT_QUEUE_SPILL && value >= 0 && value <= kSpillBlocksMax) {
@@ -4242,7 +3849,7 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     }
   }
   ctx->list_dim = 0;
-  if (ctx->reflect_table && n_spheres >= kGridFrom) {   // many spheres: the direction table as lists; the grid only if that fails
+  if (ctx->reflect_table && n_spheres >= kGridFrom) {   // many spheres: the direction table as lists
     std::vector<uint32_t> start;
     std::vector<uint2> items;
     if (build_reflect_lists(geom4, n_spheres, kReflListDim, start, items)) {
@@ -4265,21 +3872,7 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
     }
   }
   {
-    SphereGrid grid;
-    if (ctx->sphere_grid && ctx->list_dim == 0) build_sphere_grid(geom4, n_spheres, grid);
-    if (grid.dim > 0) {
-      RT_HIP(ctx, hipMemcpy(ctx->d_grid_start, grid.start.data(), sizeof(uint32_t) * grid.start.size(), hipMemcpyHostToDevice));
-      if (!grid.items.empty())
-        RT_HIP(ctx, hipMemcpy(ctx->d_grid_items, grid.items.data(), sizeof(uint16_t) * grid.items.size(), hipMemcpyHostToDevice));
-      if (!grid.big.empty())
-        RT_HIP(ctx, hipMemcpy(ctx->d_grid_big, grid.big.data(), sizeof(uint16_t) * grid.big.size(), hipMemcpyHostToDevice));
-      for (int k = 0; k < 3; ++k) { ctx->grid_min[k] = grid.mn[k]; ctx->grid_inv_cell[k] = grid.inv_cell[k]; ctx->grid_cell[k] = grid.cell[k]; }
-    }
-    ctx->grid_dim = grid.dim;
-    ctx->grid_n_big = int(grid.big.size());
-  }
-  {
-    const int B = (ctx->reflect_table && ctx->grid_dim == 0) ? reflect_table_dim(n_spheres) : 0;
+    const int B = ctx->reflect_table ? reflect_table_dim(n_spheres) : 0;
     ctx->refl_dim = 0;
     if (B > 0) {
       std::vector<uint2> tab;

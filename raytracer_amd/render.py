@@ -40,7 +40,7 @@ class Renderer:
         _lib.check(self._L.rt_create(self.device, ctypes.byref(h)))
         self._h = h
         self._packed: PackedScene | None = None
-        self._options = {"occluder_table": True, "sphere_grid": True, "reflect_table": True}     # options that take effect at upload time
+        self._options = {"occluder_table": True, "reflect_table": True}     # options that take effect at upload time
         self._uploaded_options = None
         self.use_torch_stream()
 
@@ -220,15 +220,10 @@ class Renderer:
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_OCCLUDER_TABLE, 1 if on else 0))
         self._options["occluder_table"] = bool(on)
 
-    def set_sphere_grid(self, on: bool):
-        """Reflection rays of many-sphere scenes walk a uniform grid (default) or test every sphere; same
-        images.  Takes effect at the next upload_scene."""
-        self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_SPHERE_GRID, 1 if on else 0))
-        self._options["sphere_grid"] = bool(on)
-
     def set_reflect_table(self, on: bool):
-        """Reflection rays of scenes with 4..255 spheres test only the spheres a per-object direction table lists
-        (default) or every sphere; same images.  Takes effect at the next upload_scene."""
+        """Reflection rays of scenes with 4 or more spheres test only the spheres a per-object direction table lists
+        (default; bit masks up to 255 spheres, lists from 256 on) or every sphere; same images.  Takes effect at the
+        next upload_scene."""
         self._check(self._L.rt_set_option(self._h, _lib.RT_OPT_REFLECT_TABLE, 1 if on else 0))
         self._options["reflect_table"] = bool(on)
 

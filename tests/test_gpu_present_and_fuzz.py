@@ -78,8 +78,8 @@ def _random_lights(rng, sc, sph):
 @pytest.mark.parametrize("case", range(10))
 def test_fuzz_culls_and_tables_change_no_byte(renderer, case):
     """tools/fuzz_culls.py in short: a random scene (3 .. 2040 spheres, lights next to / inside / far from spheres, a
-    random camera) rendered by the default path, without the occluder table, without the direction table, without
-    table and grid, and by the one-thread-per-pixel kernel (linear scans): identical frames and hit maps."""
+    random camera) rendered by the default path, without the occluder table, without the direction table (plain scans of
+    every sphere), and by the one-thread-per-pixel kernel (linear scans): identical frames and hit maps."""
     import torch
     rng = np.random.default_rng(1000 + case)
     n = int([3, 8, 20, 64, 150, 400, 1000, 2040, 64, 300][case])
@@ -95,14 +95,13 @@ def test_fuzz_culls_and_tables_change_no_byte(renderer, case):
         w, h = min(w, 240), min(h, 135)
     outs = []
     try:
-        for table, kernel, refl, grid in ((True, "stream", True, True), (False, "stream", True, True), (True, "stream", False, True),
-                                          (True, "stream", False, False), (True, "pixel", True, True)):
+        for table, kernel, refl in ((True, "stream", True), (False, "stream", True), (True, "stream", False), (False, "stream", False),
+                                    (True, "pixel", True)):
             renderer.set_occluder_table(table); renderer.set_kernel(kernel); renderer.set_reflect_table(refl)
-            renderer.set_sphere_grid(grid); renderer.upload_scene(sc)
+            renderer.upload_scene(sc)
             outs.append(renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True))
     finally:
         renderer.set_kernel("stream"); renderer.set_occluder_table(True); renderer.set_reflect_table(True)
-        renderer.set_sphere_grid(True)
     for i, o in enumerate(outs[1:]):
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), (case, n, w, h, D, i + 1)
 

@@ -252,36 +252,9 @@ def test_occluder_table_changes_no_byte(renderer):
         renderer.set_occluder_table(True)
 
 
-def test_sphere_grid_changes_no_byte(renderer):
-    """Reflection rays through the uniform grid (scenes with >= 256 spheres) find the same hits as the plain
-    scan: byte-identical frames and hit maps with RT_OPT_SPHERE_GRID on and off, depth up to 8, other cameras,
-    and a scene with two huge spheres (listed as `big`, tested up front)."""
-    import torch
-    from raytracer_amd.scenes import Material, Sphere, Vector3
-    big = generate_scene(300, 11)
-    big["spheres"].append(Sphere(Vector3(0, -1004, -10), 1000, Material(Vector3(0.8, 0.8, 0.8), specular=0.3, reflection=0.4)))
-    big["spheres"].insert(5, Sphere(Vector3(30, 0, -40), 25, Material(Vector3(0.9, 0.5, 0.5), specular=0.3, reflection=0.6)))
-    cases = [(generate_scene(256, 4), 640, 360, 5), (generate_scene(400, 5), 640, 360, 8), (generate_scene(1024, 3), 960, 540, 5),
-             (generate_scene(2000, 6), 480, 270, 3), (big, 640, 360, 6)]
-    try:
-        renderer.set_reflect_table(False)       # (the direction lists would take the grid's place)
-        for scene, w, h, D in cases:
-            out = []
-            for on in (True, False):
-                renderer.set_sphere_grid(on)
-                renderer.upload_scene(scene)
-                out.append([renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=3, camera=cam, return_hit_index=True)
-                            for cam in (None, orbit_camera(37, 256), orbit_camera(150, 256, radius=14.0))])
-            for (a, ha), (b, hb) in zip(*out):
-                assert torch.equal(a, b) and torch.equal(ha, hb)
-    finally:
-        renderer.set_sphere_grid(True)
-        renderer.set_reflect_table(True)
-
-
 def test_reflect_lists_change_no_byte(renderer):
     """Scenes with 256 spheres or more: reflection rays through the direction table in its list form find the same
-    hits as the plain scan (RT_OPT_REFLECT_TABLE and RT_OPT_SPHERE_GRID both off): byte-identical frames and hit
+    hits as the plain scan (RT_OPT_REFLECT_TABLE off): byte-identical frames and hit
     maps, depth up to 8, other cameras, a scene with two huge spheres (they reach every direction of their
     neighbours and list every sphere themselves), 2000 spheres."""
     import torch
@@ -292,7 +265,6 @@ def test_reflect_lists_change_no_byte(renderer):
     cases = [(generate_scene(256, 4), 640, 360, 5), (generate_scene(400, 5), 640, 360, 8), (generate_scene(1024, 3), 960, 540, 5),
              (generate_scene(2000, 6), 480, 270, 3), (big, 640, 360, 6)]
     try:
-        renderer.set_sphere_grid(False)
         for scene, w, h, D in cases:
             out = []
             for on in (True, False):
@@ -307,7 +279,6 @@ def test_reflect_lists_change_no_byte(renderer):
             for (a, ha), (b, hb) in zip(fa, fb):
                 assert torch.equal(a, b) and torch.equal(ha, hb)
     finally:
-        renderer.set_sphere_grid(True)
         renderer.set_reflect_table(True)
 
 

@@ -1,6 +1,6 @@
 """GPU box: randomized check that none of the culls and tables changes a byte.  Random scenes (sphere count, light
 positions and sizes — also lights next to or inside spheres —, cameras); each is rendered by the default
-path, with the occluder table off, with the direction table off (and the grid off), and by the
+path, with the occluder table off, with the direction table off, and by the
 one-thread-per-pixel kernel (linear primary scan, plain reflection scan, same shading): frames and hit maps must be
 identical."""
 import os, sys
@@ -41,12 +41,12 @@ for case in range(n_cases):
     if only >= 0 and case != only:
         continue
     outs = []
-    # default path / no occluder table / no direction table (grid from 256 spheres) / neither table nor grid / pixel kernel
-    for table, kernel, refl, grid in ((True, "stream", True, True), (False, "stream", True, True), (True, "stream", False, True),
-                                      (True, "stream", False, False), (True, "pixel", True, True)):
-        r.set_occluder_table(table); r.set_kernel(kernel); r.set_reflect_table(refl); r.set_sphere_grid(grid); r.upload_scene(sc)
+    # default path / no occluder table / no direction table / neither / pixel kernel
+    for table, kernel, refl in ((True, "stream", True), (False, "stream", True), (True, "stream", False), (False, "stream", False),
+                                (True, "pixel", True)):
+        r.set_occluder_table(table); r.set_kernel(kernel); r.set_reflect_table(refl); r.upload_scene(sc)
         outs.append(r.render(w, h, 1, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True))
-    r.set_kernel("stream"); r.set_occluder_table(True); r.set_reflect_table(True); r.set_sphere_grid(True)
+    r.set_kernel("stream"); r.set_occluder_table(True); r.set_reflect_table(True)
     same = all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
     if not same:
         ref = outs[-1]
