@@ -27,11 +27,16 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-munsafe-fp-atomics"]   # hardware float atomics for the refraction path's pixel sums
 
 
+def sources() -> list[str]:
+    """rt355.hip and the parts it includes (one translation unit), plus the public header."""
+    return [SRC, HDR] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+
+
 def needs_build() -> bool:
     if not os.path.isfile(SO):
         return True
     t = os.path.getmtime(SO)
-    return any(os.path.getmtime(f) > t for f in (SRC, HDR))
+    return any(os.path.getmtime(f) > t for f in sources())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

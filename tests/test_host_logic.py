@@ -117,7 +117,7 @@ def test_no_gpu_means_loud_failure():
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "raytracer_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/", "").lower() or f in ("__init__.py",) \
                     or "import oracle" not in src and "from oracle" not in src, f
