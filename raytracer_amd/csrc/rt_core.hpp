@@ -140,7 +140,11 @@ constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shad
 #else
 #define RT_NOW() 0ull
 #endif
-constexpr int kShadowBatch = 13;   // 1 point-light ray + 12 area-light rays (raytracer.py:80)
+#ifndef RT_SHADOW_BATCH
+#define RT_SHADOW_BATCH 13
+#endif
+constexpr int kShadowBatch = RT_SHADOW_BATCH;   // shadow rays traced together: 1 point-light ray + 12 area-light rays (raytracer.py:80) by default
+constexpr int kReferenceShadowRays = 13;
 #ifndef RT_REFR_BATCH
 #define RT_REFR_BATCH 7
 #endif

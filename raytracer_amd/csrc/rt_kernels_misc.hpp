@@ -199,6 +199,48 @@ __global__ __launch_bounds__(256) void rt_place_tiles_kernel(const uint8_t* __re
   const int tiles8_x = (width + 7) / 8, pitch = tiles8_x | 1;
   const int n_tiles = (height + tile_rows - 1) / tile_rows;
   const int row_bytes = width * 3;
+  if (vec4 == 2 && (tile_rows & 7) == 0) {
+    // The common case — row tiles of a multiple of 8 rows, rows of a multiple of 16 bytes, 16-byte aligned frames: the 8 rows
+    // of the band lie in ONE row tile of one rank, so the band's index arithmetic (several integer divisions) and a lane's
+    // table look-ups are done once and serve 8 rows.  A lane owns 16-byte columns of the band: four dwords from at most two
+    // tiles (a tile row is 24 bytes, so the columns fall 0 / 16 / 8 bytes into a tile with a period of three), eight
+    // independent loads and eight global_store_dwordx4; where both tiles are black — four fifths of config 2's — no load.
+    const int y0 = int(blockIdx.x) * 8, rows = min(8, height - y0);
+    const int t = y0 / tile_rows, rank = t % n_ranks;
+    const int lr0 = (t / n_ranks) * tile_rows + (y0 - t * tile_rows);          // (a multiple of 8)
+    const int mine = n_tiles > rank ? (n_tiles - rank + n_ranks - 1) / n_ranks : 0;
+    const int rows_r = mine * tile_rows - (((n_tiles - 1) % n_ranks == rank) ? n_tiles * tile_rows - height : 0);
+    const int tiles8_y = (rows_r + 7) / 8;
+    const uint32_t* trow = table + (long long)rank * ids_per_rank + (long long)frame * pitch * tiles8_y + (long long)(lr0 >> 3) * pitch;
+    const uint8_t* ebase = entries + size_t(rank) * capacity * kTileEntryBytes + 4;
+    uint8_t* dst = out + ((long long)frame * height + y0) * row_bytes;
+    for (int c = threadIdx.x; c < row_bytes / 16; c += blockDim.x) {
+      const int d0 = 4 * c, tx0 = d0 / 6, tx1 = (d0 + 3) / 6;
+      const uint32_t s0 = trow[tx0], s1 = tx1 == tx0 ? s0 : trow[tx1];
+      const uint8_t* e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = d0 + k, tx = d / 6, dw = d - 6 * tx;
+        const uint32_t slot = tx == tx0 ? s0 : s1;
+        e[k] = slot ? ebase + size_t(slot - 1u) * kTileEntryBytes + dw * 4 : nullptr;
+      }
+      uint4 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        v[r] = make_uint4(0u, 0u, 0u, 0u);
+        if ((s0 | s1) != 0u && r < rows) {
+          if (e[0]) v[r].x = *reinterpret_cast<const uint32_t*>(e[0] + r * 24);
+          if (e[1]) v[r].y = *reinterpret_cast<const uint32_t*>(e[1] + r * 24);
+          if (e[2]) v[r].z = *reinterpret_cast<const uint32_t*>(e[2] + r * 24);
+          if (e[3]) v[r].w = *reinterpret_cast<const uint32_t*>(e[3] + r * 24);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r < rows) reinterpret_cast<uint4*>(dst + (long long)r * row_bytes)[c] = v[r];
+    }
+    return;
+  }
   for (int y = int(blockIdx.x) * 8; y < min(height, int(blockIdx.x) * 8 + 8); ++y) {
     const int t = y / tile_rows, rank = t % n_ranks;
     const int lr = (t / n_ranks) * tile_rows + (y - t * tile_rows);
@@ -209,7 +251,23 @@ __global__ __launch_bounds__(256) void rt_place_tiles_kernel(const uint8_t* __re
     const uint32_t* trow = table + (long long)rank * ids_per_rank + (long long)frame * pitch * tiles8_y + (long long)(lr >> 3) * pitch;
     const uint8_t* erow = entries + size_t(rank) * capacity * kTileEntryBytes + 4 + (lr & 7) * 24;
     uint8_t* dst = out + ((long long)frame * height + y) * row_bytes;
-    if (vec4) {
+    if (vec4 == 2) {
+      // sixteen bytes per lane and store (rows of a multiple of 16 bytes, 16-byte aligned frames): four dwords from at most two
+      // tiles — a tile row is 24 bytes, so chunks fall 0 / 16 / 8 bytes into a tile with a period of three — and one
+      // global_store_dwordx4; a band of a mostly black frame is written at the rate of a clear
+      for (int c = threadIdx.x; c < row_bytes / 16; c += 256) {
+        uint32_t v[4];
+        const int d0 = 4 * c, tx0 = d0 / 6, tx1 = (d0 + 3) / 6;
+        const uint32_t s0 = trow[tx0], s1 = tx1 == tx0 ? s0 : trow[tx1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = d0 + k, tx = d / 6, dw = d - 6 * tx;
+          const uint32_t slot = tx == tx0 ? s0 : s1;
+          v[k] = slot ? *reinterpret_cast<const uint32_t*>(erow + size_t(slot - 1u) * kTileEntryBytes + dw * 4) : 0u;
+        }
+        reinterpret_cast<uint4*>(dst)[c] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+    } else if (vec4) {
       for (int w = threadIdx.x; w < row_bytes / 4; w += 256) {
         const int tx = w / 6, dw = w - 6 * tx;
         const uint32_t slot = trow[tx];

@@ -73,7 +73,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
   // batch holds the point-light ray, so its survivors are a superset of every later batch's: the later batches test these
   // without culling again, and a ray that hits objects of BOTH kinds finds its nearest hit among them (no other object can
   // be hit by any of the point's shadow rays).
-  constexpr bool SHARE = REFR || B < kShadowBatch;     // (the reference's 13 rays in one batch: nothing to share, no registers held)
+  constexpr bool SHARE = REFR || B < kReferenceShadowRays;     // (the reference's 13 rays in one batch: nothing to share, no registers held)
   [[maybe_unused]] uint32_t kept0 = 0u, kept1 = 0u, keptc = 0u;
   for (int base = 0; base < nrays; base += B) {
     float Lx[B], Ly[B], Lz[B], m[B];

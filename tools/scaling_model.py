@@ -1,0 +1,88 @@
+"""GPU box, ONE GPU: the pieces of an N-GPU row-tile step measured one by one, and the scaling curve they predict
+(DESIGN.md 7).  For each workload and N in 1, 2, 4, 8: rank 0's render share of a batch (tile_first = 0, tile_stride = N),
+rt_compact_tiles of its slab, the bytes a rank hands to the gather, and rt_place_tiles of all N ranks' entries on the root
+(every rank's share is rendered here, one after another, to have real entries).  Model of the steady state of the
+pipelined exchange (raytracer_amd/distributed.py): a batch leaves every
+    period(N) = max( render + compact [any rank],  bytes per rank / link rate [each peer has its own xGMI link into GPU 0],
+                     root: render + compact + place  [serial: the pessimistic end] or max(render + compact, place) [overlapped] )
+    python tools/scaling_model.py [workloads...] > profiles/r3_scaling_model.txt"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bench
+from raytracer_amd import tiling
+from raytracer_amd._lib import TILE_ENTRY_BYTES
+from raytracer_amd.render import Renderer
+from raytracer_amd.scenes import Camera
+
+LINK_GBS = 153.0          # one xGMI link, one direction (MI355X_MICROARCH.md)
+tr = 8
+r = Renderer(0)
+
+
+def timed(fn, reps=5):
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return min(ts[1:])
+
+
+for wl in (sys.argv[1:] or ["c2", "t64", "c4"]):
+    w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
+    F = 16 if wl == "c4" else 256
+    r.upload_scene(bench.build_scene(wl))
+    cams = r.pack_cameras([Camera()] * F)
+    print(f"## {wl}: {desc}; batches of {F} frames, row tiles of {tr} rows")
+    print("| N | render share ms | compact ms | occupied tiles of rank 0 | MB per rank | link ms @153 GB/s | place ms (root) | period serial ms | "
+          "period overlapped ms | bound (serial / overlapped) | frames/s serial | frames/s overlapped | speed-up serial / overlapped |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    base = None
+    for G in (1, 2, 4, 8):
+        rows_max = tiling.max_local_rows(h, tr, G)
+        cap = F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8)
+        slabs = [torch.empty((F, rows_max, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(1)]
+        entries = torch.empty((G, cap, TILE_ENTRY_BYTES), dtype=torch.uint8, device="cuda:0")
+        counts = torch.zeros(G, dtype=torch.int32, device="cuda:0")
+        t_render = t_compact = None
+        for rank in range(G):
+            def render():
+                r.render_frames(cams, range(F), w, h, 1, max_depth=D, out=slabs[0], tile_rows=tr, tile_first=rank, tile_stride=G)
+            def compact():
+                r.compact_tiles(slabs[0], entries[rank], counts[rank:rank + 1])
+            if rank == 0:
+                t_render = timed(render)
+                render()
+                t_compact = timed(compact)
+            else:
+                render(); compact()
+        torch.cuda.synchronize()
+        cnt = [int(c) for c in counts.tolist()]
+        nmax = max(cnt)
+        gathered = entries[:, :max(nmax, 1)].contiguous()
+        out = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0")
+        table = {}
+        def place():
+            table["t"] = r.place_tiles(gathered, counts, w, h, tr, out, table.get("t"))
+        t_place = timed(place) if G > 1 else 0.0
+        mb = nmax * TILE_ENTRY_BYTES / 1e6
+        t_link = mb / 1e3 / LINK_GBS * 1e3 if G > 1 else 0.0
+        if G == 1:
+            t_compact_eff = 0.0          # (a single GPU renders into the frames: no exchange)
+        else:
+            t_compact_eff = t_compact
+        work = t_render + t_compact_eff
+        serial = max(work, t_link, work + t_place)
+        overl = max(work, t_link, t_place)
+        def bound(per, root):
+            if per == t_link: return "link"
+            if per == root and root > work + 1e-9: return "root placement"
+            return "render"
+        fs_s, fs_o = F / serial * 1e3, F / overl * 1e3
+        if base is None: base = fs_s
+        print(f"| {G} | {t_render:.2f} | {t_compact:.2f} | {cnt[0]} | {mb:.1f} | {t_link:.2f} | {t_place:.2f} | {serial:.2f} | {overl:.2f} | "
+              f"{bound(serial, work + t_place)} / {bound(overl, t_place)} | {fs_s:.0f} | {fs_o:.0f} | {fs_s / base:.2f} / {fs_o / base:.2f} |")
+        del slabs, entries, gathered, out
+        torch.cuda.empty_cache()
+    print()
