@@ -149,7 +149,7 @@ def single_frame(r, wl):
     """The reference's API renders ONE frame (raytracer.py:310): time the drop-in call — scene check (an unchanged scene is
     not uploaded again), one launch pair for one frame, copy of the frame to a pinned host array."""
     import raytracer_amd
-    from raytracer_amd import render as render_mod
+    render_mod = sys.modules["raytracer_amd.render"]       # (the package exports the FUNCTION render under that name)
     w, h, _, _, _, D, _ = WORKLOADS[wl]
     scene = build_scene(wl)
     saved = render_mod.scene
