@@ -110,7 +110,9 @@ struct rt_ctx {
   bool sums_never_negative() const { return nonneg_scene && nonneg_refr && nonneg_cubes; }
   uint2* d_refl_tab = nullptr;        // direction table of reflection rays (build_reflect_table; grown on demand)
   size_t refl_tab_bytes = 0;
-  int refl_dim = 0, refl_pairs = 0;
+  int refl_dim = 0, refl_pairs = 0, refl_cpairs = 0;
+  int refl_boxes = 0;                 // boxes the table was built with (it serves a scene with cubes only if they are these)
+  std::vector<float> h_geom;          // the uploaded spheres (cx cy cz r^2), kept for rt_set_cubes' rebuild of the table
   uint32_t* d_occl_start = nullptr;   // occluder table rows as lists (scenes with >= kGridFrom spheres): [RT_MAX_SPHERES + 1]
   uint2* d_occl_items = nullptr;      // (grown on demand)
   size_t occl_items_bytes = 0;
@@ -407,8 +409,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.glass_bits = ctx->d_glass_bits;
   p.list_start = ctx->d_list_start; p.list_items = ctx->d_list_items;
   p.list_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->list_dim;
-  p.refl_tab = ctx->d_refl_tab; p.refl_pairs = ctx->refl_pairs;
-  p.refl_dim = (cubes || !stream_kernel || listed) ? 0 : ctx->refl_dim;
+  p.refl_tab = ctx->d_refl_tab; p.refl_pairs = ctx->refl_pairs; p.refl_cpairs = ctx->refl_cpairs;
+  p.refl_dim = (!stream_kernel || listed || ctx->refl_boxes != ctx->n_cubes) ? 0 : ctx->refl_dim;
   p.defer_output = (refr && !refr_slots) ? 1 : 0;
   p.tile_flush = slots ? 1 : 0;
   p.accum = ctx->d_accum;
@@ -555,6 +557,27 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
       RT_HIP(ctx, hipGetLastError());
     }
   }
+  return RT_OK;
+}
+
+// The direction table of secondary rays (bit-mask form, scenes of 4 .. 255 spheres) for the context's spheres and `n_boxes`
+// boxes: built on the host, copied to the device (the buffer grows on demand).
+int upload_reflect_table(rt_ctx* ctx, const float4* boxes, int n_boxes) {
+  const int n = int(ctx->h_geom.size() / 4);
+  const int B = ctx->reflect_table ? reflect_table_dim(n, n_boxes) : 0;
+  ctx->refl_dim = 0; ctx->refl_boxes = 0;
+  if (B == 0) return RT_OK;
+  std::vector<uint2> tab;
+  build_reflect_table(ctx->h_geom.data(), n, B, tab, boxes, n_boxes);
+  const size_t bytes = tab.size() * sizeof(uint2);
+  if (bytes > ctx->refl_tab_bytes) {
+    if (ctx->d_refl_tab) (void)hipFree(ctx->d_refl_tab);
+    ctx->d_refl_tab = nullptr; ctx->refl_tab_bytes = 0;
+    RT_HIP(ctx, hipMalloc(&ctx->d_refl_tab, bytes));
+    ctx->refl_tab_bytes = bytes;
+  }
+  RT_HIP(ctx, hipMemcpy(ctx->d_refl_tab, tab.data(), bytes, hipMemcpyHostToDevice));
+  ctx->refl_dim = B; ctx->refl_pairs = (n + 63) / 64; ctx->refl_cpairs = (n_boxes + 63) / 64; ctx->refl_boxes = n_boxes;
   return RT_OK;
 }
 
@@ -814,23 +837,8 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
       ctx->list_dim = kReflListDim;
     }
   }
-  {
-    const int B = ctx->reflect_table ? reflect_table_dim(n_spheres) : 0;
-    ctx->refl_dim = 0;
-    if (B > 0) {
-      std::vector<uint2> tab;
-      build_reflect_table(geom4, n_spheres, B, tab);
-      const size_t bytes = tab.size() * sizeof(uint2);
-      if (bytes > ctx->refl_tab_bytes) {
-        if (ctx->d_refl_tab) (void)hipFree(ctx->d_refl_tab);
-        ctx->d_refl_tab = nullptr; ctx->refl_tab_bytes = 0;
-        RT_HIP(ctx, hipMalloc(&ctx->d_refl_tab, bytes));
-        ctx->refl_tab_bytes = bytes;
-      }
-      RT_HIP(ctx, hipMemcpy(ctx->d_refl_tab, tab.data(), bytes, hipMemcpyHostToDevice));
-      ctx->refl_dim = B; ctx->refl_pairs = (n_spheres + 63) / 64;
-    }
-  }
+  ctx->h_geom.assign(geom4, geom4 + size_t(4) * size_t(n_spheres));   // (rt_set_cubes builds the table again, with the boxes)
+  if (int rc = upload_reflect_table(ctx, nullptr, 0)) return rc;
   RT_HIP(ctx, hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32)));
   {   // can a node of a pixel's tree contribute a negative share?  (see rt_ctx::sums_never_negative)
     bool ok = lights->point_intensity >= 0.f && lights->area_intensity >= 0.f;
@@ -890,6 +898,9 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
                             hipMemcpyHostToDevice));
     }
   }
+  ctx->n_cubes = 0;
+  // secondary rays of a scene with boxes: the direction table again, with the boxes as sources and targets
+  if (int rc = upload_reflect_table(ctx, n_cubes > 0 ? box.data() : nullptr, n_cubes)) return rc;
   ctx->n_cubes = n_cubes;
   ctx->has_refr_cubes = any;
   ctx->nonneg_cubes = nonneg;

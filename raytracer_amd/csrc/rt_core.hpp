@@ -74,6 +74,7 @@ struct RenderParams {
   // masks of the spheres a ray that leaves the object in a direction of the bucket can hit (nearest_table)
   const uint2* refl_tab;
   int refl_dim, refl_pairs;
+  int refl_cpairs;       // ... followed by this many 64-bit masks of the BOXES such a ray's line can cross (scenes with cubes)
   // the same table as lists, for scenes with too many spheres for masks (list_dim = 0: none): entry [object][bucket] is the
   // run of 4-index chunks list_start[e] .. list_start[e + 1] of list_items (uint16 indices, ascending, padded with 0xFFFF)
   const uint32_t* list_start;
@@ -425,15 +426,17 @@ __device__ __forceinline__ int direction_bucket(float dx, float dy, float dz, in
   const int iy = min(B - 1, max(0, int(fmaf(b * inv, hB, hB))));
   return ((2 * m + (major < 0.0f ? 1 : 0)) * B + iy) * B + ix;
 }
+template <bool CUBES = false>
 __device__ __forceinline__ void nearest_table(const RenderParams& p, const float4* __restrict__ sg, int obj, float ox,
                                               float oy, float oz, float dx, float dy, float dz, float& best_t,
-                                              int& best_i) {
+                                              int& best_i, int& best_face) {
   const float inv_a = frcp(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
   best_t = INFINITY;
   best_i = -1;
+  best_face = 0;
   const int B = p.refl_dim;
   const int bucket = direction_bucket(dx, dy, dz, B);
-  const uint2* row = p.refl_tab + (size_t(obj) * size_t(6 * B * B) + size_t(bucket)) * size_t(p.refl_pairs);
+  const uint2* row = p.refl_tab + (size_t(obj) * size_t(6 * B * B) + size_t(bucket)) * size_t(p.refl_pairs + (CUBES ? p.refl_cpairs : 0));
   for (int w = 0; w < p.refl_pairs; ++w) {
     const uint2 mask = row[w];
     uint32_t lo = mask.x, hi = mask.y;
@@ -447,6 +450,29 @@ __device__ __forceinline__ void nearest_table(const RenderParams& p, const float
         float dl;
         const float t = sphere_t_exact(sg[j], ox, oy, oz, dx, dy, dz, inv_a, dl);
         if (dl >= 0.0f && t > 0.0f && t < best_t) { best_t = t; best_i = j; }
+      }
+    }
+  }
+  if constexpr (CUBES) {
+    // the boxes the entry lists, after the spheres and in index order (nearest_object's order: same winner on ties)
+    const float ix = frcp(dx), iy = frcp(dy), iz = frcp(dz);
+    const int n = p.n_spheres;
+    for (int w = 0; w < p.refl_cpairs; ++w) {
+      const uint2 mask = row[p.refl_pairs + w];
+      uint32_t lo = mask.x, hi = mask.y;
+      while (__ballot((lo | hi) != 0u) != 0ull) {
+        if ((lo | hi) != 0u) {
+          const bool in_lo = lo != 0u;
+          uint32_t cur = in_lo ? lo : hi;
+          const int c = 64 * w + (in_lo ? 0 : 32) + __ffs(int(cur)) - 1;
+          cur &= cur - 1u;
+          if (in_lo) lo = cur; else hi = cur;
+          float t;
+          int face;
+          if (cube_t(sg[n + 2 * c], sg[n + 2 * c + 1], ox, oy, oz, dx, dy, dz, ix, iy, iz, t, face) && t < best_t) {
+            best_t = t; best_i = n + c; best_face = face;
+          }
+        }
       }
     }
   }

@@ -741,7 +741,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             float t;
             int idx2, face;
             ++n_trace;
-            if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), sx, sy, sz, rdx, rdy, rdz, t, idx2); face = 0; }
+            if (p.refl_dim > 0) nearest_table<CUBES>(p, sg, meta_object(meta), sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
             else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
             if (idx2 >= 0) {
               push_r = true;
@@ -771,7 +771,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
               int idx2, face;
               ++n_trace;
               // (the refracted ray starts 0.001 INSIDE the object: still within reach of the table's bound)
-              if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), ox, oy, oz, fdx, fdy, fdz, t, idx2); face = 0; }
+              if (p.refl_dim > 0) nearest_table<CUBES>(p, sg, meta_object(meta), ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
               else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
               if (idx2 >= 0) {
                 push_f = true;
@@ -853,7 +853,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             else nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);   // (RT_OPT_REFLECT_TABLE off, or lists beyond 256 MB)
             face = 0;
           }
-          else if (!CUBES && p.refl_dim > 0) { nearest_table(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2); face = 0; }
+          else if (p.refl_dim > 0) nearest_table<CUBES>(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2, face);
           else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, dx, dy, dz, t, idx2, face);
           if (idx2 >= 0) {
             again = true;

@@ -12,12 +12,17 @@ constexpr int kGridFrom = 256;   // scenes with at least this many spheres: shad
 // the cone (axis through its centre, half-angle h to the farthest corner), and j is listed iff
 // angle(axis, u) <= theta_kj + h + 1e-3 (the last term: the kernel's FP32 bucket arithmetic, ~1e-6).  k itself is
 // never listed: a ray that leaves a sphere outwards cannot come back to it.
+// Boxes (rt_set_cubes) take part through their bounding spheres, as objects n .. n + n_boxes - 1: as SOURCES with rho = half
+// diagonal (+ 0.001: the origin lies within that of the centre), as TARGETS with the line rule of intersect_cube — a box is
+// hit by every ray whose LINE crosses it (cube_t: t < 0 counts), so a box is listed where the bucket's cone meets the cone
+// towards it OR its mirror image; and a box lists ITSELF in every bucket (the line of a ray that leaves a face runs back
+// through the box: the reference "hits" it at t < 0; a refracted ray inside a glass box meets its exit face).
 constexpr int kReflTabFrom = RT_REFL_TABLE_FROM;   // scenes with at least this many spheres (and fewer than the grid's threshold)
 constexpr size_t kReflTabMaxBytes = size_t(1) << 20;
-int reflect_table_dim(int n) {
-  if (n < kReflTabFrom || n >= kGridFrom) return 0;
-  const size_t pairs = size_t((n + 63) / 64);
-  for (int B : {16, 8}) if (size_t(n) * size_t(6 * B * B) * pairs * 8 <= kReflTabMaxBytes) return B;
+int reflect_table_dim(int n, int n_boxes = 0) {
+  if (n + n_boxes < kReflTabFrom || n >= kGridFrom) return 0;
+  const size_t pairs = size_t((n + 63) / 64) + size_t((n_boxes + 63) / 64);
+  for (int B : {16, 8}) if (size_t(n + n_boxes) * size_t(6 * B * B) * pairs * 8 <= kReflTabMaxBytes) return B;
   return 4;
 }
 struct DirPatch { double x, y, z, ch, sh, h; };   // bounding cone of a bucket: unit axis, cos / sin of its half-angle h (margin included)
@@ -47,15 +52,21 @@ std::vector<DirPatch> direction_patches(int B) {
 // The buckets of object k, sphere by sphere: emit(bucket, j) for every bucket that lists j, j ascending.  Buckets are
 // looked at through a coarse level (4 x 4 patches per face, each the union of (B/4)^2 buckets) when B allows it:
 // most spheres reach into one or two coarse patches only.
+// (`geom4`: the n spheres, then the bounding spheres of the boxes: centre, radius^2; objects from n_spheres on are boxes)
 template <typename Emit>
 void reflect_buckets_of(const float* geom4, int n, int k, int B, const std::vector<DirPatch>& fine,
-                        const std::vector<DirPatch>& coarse, Emit&& emit) {
+                        const std::vector<DirPatch>& coarse, Emit&& emit, int n_spheres = -1) {
+  if (n_spheres < 0) n_spheres = n;
   const double kPi = 3.14159265358979323846;
   const int nb = 6 * B * B, Bc = coarse.empty() ? 0 : 4, sub = Bc ? B / Bc : 0;
   const double kx = geom4[4 * k], ky = geom4[4 * k + 1], kz = geom4[4 * k + 2];
   const double rho = std::sqrt(double(geom4[4 * k + 3])) * 1.001 + 2e-3;
   for (int j = 0; j < n; ++j) {
-    if (j == k) continue;
+    const bool box = j >= n_spheres;
+    if (j == k) {
+      if (box) for (int b = 0; b < nb; ++b) emit(b, j);       // a box lists itself everywhere (see above)
+      continue;
+    }
     const double vx = geom4[4 * j] - kx, vy = geom4[4 * j + 1] - ky, vz = geom4[4 * j + 2] - kz;
     const double d = std::sqrt(vx * vx + vy * vy + vz * vz);
     const double reach = rho + std::sqrt(double(geom4[4 * j + 3])) * 1.001 + 1e-3;
@@ -64,7 +75,8 @@ void reflect_buckets_of(const float* geom4, int n, int k, int B, const std::vect
     const double ux = all ? 0.0 : vx / d, uy = all ? 0.0 : vy / d, uz = all ? 0.0 : vz / d;
     // angle(axis, u) <= theta + h  <=>  axis.u >= cos(theta + h)   (theta + h < pi)
     auto reaches = [&](const DirPatch& P) {
-      return all || theta + P.h >= kPi || P.x * ux + P.y * uy + P.z * uz >= cs * P.ch - sn * P.sh;
+      const double along = P.x * ux + P.y * uy + P.z * uz;
+      return all || theta + P.h >= kPi || (box ? std::fabs(along) : along) >= cs * P.ch - sn * P.sh;   // (box: the cone or its mirror image)
     };
     if (!Bc) {
       for (int b = 0; b < nb; ++b) if (reaches(fine[size_t(b)])) emit(b, j);
@@ -82,16 +94,26 @@ void reflect_buckets_of(const float* geom4, int n, int k, int B, const std::vect
         }
   }
 }
-void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& tab) {
-  const int pairs = (n + 63) / 64, nb = 6 * B * B;
-  tab.assign(size_t(n) * size_t(nb) * size_t(pairs), make_uint2(0u, 0u));
+// Entry [k][bucket] = ceil(n / 64) pairs of sphere bits, then ceil(n_boxes / 64) pairs of box bits.  `boxes`: n_boxes x {min
+// xyz -, max xyz -} as rt_set_cubes stores them, or null.
+void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& tab, const float4* boxes = nullptr, int n_boxes = 0) {
+  const int pairs_s = (n + 63) / 64, pairs = pairs_s + (n_boxes + 63) / 64, nb = 6 * B * B, n_obj = n + n_boxes;
+  tab.assign(size_t(n_obj) * size_t(nb) * size_t(pairs), make_uint2(0u, 0u));
   const std::vector<DirPatch> fine = direction_patches(B);
   const std::vector<DirPatch> coarse = (B > 4 && B % 4 == 0) ? direction_patches(4) : std::vector<DirPatch>();
-  for (int k = 0; k < n; ++k)
-    reflect_buckets_of(geom4, n, k, B, fine, coarse, [&](int b, int j) {
-      uint2& e = tab[(size_t(k) * size_t(nb) + size_t(b)) * size_t(pairs) + size_t(j >> 6)];
-      if (j & 32) e.y |= 1u << (j & 31); else e.x |= 1u << (j & 31);
-    });
+  std::vector<float> obj(geom4, geom4 + size_t(4) * size_t(n));
+  for (int c = 0; c < n_boxes; ++c) {          // bounding spheres, rounded UP (float centre: half an ulp is inside the table's margins)
+    const float4 lo = boxes[2 * c], hi = boxes[2 * c + 1];
+    const double hx = 0.5 * (double(hi.x) - lo.x), hy = 0.5 * (double(hi.y) - lo.y), hz = 0.5 * (double(hi.z) - lo.z);
+    obj.push_back(float(lo.x + hx)); obj.push_back(float(lo.y + hy)); obj.push_back(float(lo.z + hz));
+    obj.push_back(float((hx * hx + hy * hy + hz * hz) * 1.001 + 1e-6));
+  }
+  for (int k = 0; k < n_obj; ++k)
+    reflect_buckets_of(obj.data(), n_obj, k, B, fine, coarse, [&](int b, int j) {
+      const int w = j < n ? (j >> 6) : pairs_s + ((j - n) >> 6), bit = j < n ? (j & 63) : ((j - n) & 63);
+      uint2& e = tab[(size_t(k) * size_t(nb) + size_t(b)) * size_t(pairs) + size_t(w)];
+      if (bit & 32) e.y |= 1u << (bit & 31); else e.x |= 1u << (bit & 31);
+    }, n);
 }
 // The table as lists (nearest_list): start[k * nb + b] .. start[k * nb + b + 1] are the 4-index chunks of entry
 // [k][b] in `items` (ascending sphere indices, the last chunk padded with 0xFFFF).  Objects are independent, so the

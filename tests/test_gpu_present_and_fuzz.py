@@ -155,6 +155,15 @@ def test_fuzz_cubes_against_oracle(renderer, oracle, case):
     o = oracle.render_scene(sc, w, h, samples=1, max_depth=D, mode="K", seed=case, camera=None if cam is None else cam.as_array())
     check_hits(hit.cpu().numpy(), o["hit"], o["margin"])
     check_rgb(img.cpu().numpy(), o["rgb8"])
+    # the direction table of secondary rays with boxes as sources and targets (line rule, a box lists itself): the plain
+    # scan of every object finds the same hits, so the frame is the same byte for byte (refractive sums are integers)
+    import torch
+    try:
+        renderer.set_reflect_table(False); renderer.upload_scene(sc)
+        img2, hit2 = renderer.render(w, h, 1, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True)
+    finally:
+        renderer.set_reflect_table(True)
+    assert torch.equal(hit, hit2) and torch.equal(img, img2), (case, n, len(objs), w, h, D)
 
 
 @pytest.mark.parametrize("case", range(10))
