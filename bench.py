@@ -234,6 +234,38 @@ def main():
     if os.environ.get("RT_BENCH_NO_TILE_FLUSH"):  # A/B of the stream kernel's coalesced output path
         r.set_tile_flush(False)
     buffers = {}                                # frame / exchange buffers, reused by workloads of the same size
+    # The collectives of the N > 1 step run inside librt355 (rt_comm_*: the library's own RCCL communicator, SURVEY.md
+    # 5 / 8b) unless RT_BENCH_COMM=torch asks for torch.distributed's; torch.distributed stays for the rendezvous, the
+    # barrier and the timing reduction.  The communicator is tried once on known values before any timed work; if a rank
+    # could not join or a value came out wrong, every rank falls back to torch.distributed's collectives and the JSON
+    # line says so.
+    comm, comm_note = None, "none (single GPU)"
+    if world > 1 or force_exchange:
+        comm_note = "torch.distributed (backend %s)" % backend
+        if backend == "nccl" and os.environ.get("RT_BENCH_COMM", "abi") == "abi":
+            ok = 0
+            try:
+                r.comm_init()
+                one = torch.tensor([rank + 1], dtype=torch.int32, device=dev)
+                every = torch.zeros(world, dtype=torch.int32, device=dev)
+                r.comm_all_gather_counts(one, every)
+                send = torch.full(((rank + 1) * 196,), rank + 1, dtype=torch.uint8, device=dev)
+                got = torch.zeros((world, world * 196), dtype=torch.uint8, device=dev) if rank == 0 else None
+                r.comm_gather(send, (rank + 1) * 196, got, [(k + 1) * 196 for k in range(world)], world * 196, 0)
+                torch.cuda.synchronize()
+                ok = int(every.tolist() == list(range(1, world + 1)) and
+                         (rank != 0 or all(bool((got[k, :(k + 1) * 196] == k + 1).all()) and not bool(got[k, (k + 1) * 196:].any())
+                                           for k in range(world))))
+            except Exception as e:      # noqa: BLE001  (reported; the fallback below takes over)
+                print(f"[bench] rank {rank}: rt_comm_* unavailable: {e!r}", file=sys.stderr, flush=True)
+            agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 1:
+                comm = r
+                v = r.comm_info()["rccl_version"]
+                comm_note = f"librt355 rt_comm_* (grouped ncclSend / ncclRecv, RCCL {v // 10000}.{v // 100 % 100}.{v % 100} bound at run time)"
+            else:
+                comm_note += " — rt_comm_* failed its self-test on some rank"
 
     def measure(wl, F, B, steps, warmup, samples):
         """warmup + `steps` timed steps (of B batches of F frames) of workload `wl`; returns the numbers of the JSON line
@@ -271,7 +303,7 @@ def main():
                                                    on_current_stream=buffers["ex"].on_side)
                     buffers["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
                                                   capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
-                                                  force_collectives=force_exchange)
+                                                  force_collectives=force_exchange, comm=comm)
         ex = buffers.get("ex")
         frames_out = buffers.get("frames_out")
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -400,7 +432,7 @@ def main():
             "config": {"workload": f"{desc}; step = {B} batches of {F} frames (one launch pair each), {samples} spp, "
                                    f"keyed RNG, {n_sph} spheres, 12 area-light samples",
                        "width": w, "height": h, "max_depth": D, "frames_per_batch": F, "batches_per_step": B,
-                       "frames_per_step": F * B, "parallelism": par},
+                       "frames_per_step": F * B, "parallelism": par, "collectives": comm_note},
             "rays_per_frame": total_rays / (steps * F * B),
             "rays_per_pixel": total_rays / max(primary, 1.0),
             "mpixels_per_s": primary / dt / 1e6,

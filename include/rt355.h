@@ -267,6 +267,36 @@ int rt_place_tiles(rt_ctx* ctx, const uint8_t* entries, const uint32_t* counts_d
                    int n_frames, int width, int height, int tile_rows, uint32_t* table, int64_t table_words,
                    uint8_t* out_rgb);
 
+/* RCCL behind the C ABI (no reference counterpart: the reference has no distributed code; SURVEY.md §5 / §8(b)
+ * sketch the gather of row tiles to GPU 0 as grouped ncclSend / ncclRecv on a communicator the library owns).
+ * One process per GPU, one communicator per context.  The library binds librccl.so.1 at run time (dlopen: the copy the
+ * process has already loaded — torch's — if there is one, else the loader's search path, else RT355_RCCL_LIB), so
+ * librt355.so itself has no link-time dependency on RCCL and single-GPU users never load it.
+ *   rt_comm_unique_id   one rank (rank 0) makes the 128-byte id (ncclGetUniqueId); the host hands it to the other
+ *                       ranks by whatever means it has (raytracer_amd uses torch.distributed's store: plumbing).
+ *   rt_comm_init        collective over the n_ranks processes: ncclCommInitRank on the context's GPU.
+ *   rt_comm_destroy     collective; rt_destroy calls it for a context that still holds a communicator.
+ *   rt_comm_all_gather_counts   counts_all_dev[r] = rank r's *count_dev (one 32-bit word each: the tile counts
+ *                       rt_compact_tiles leaves on the device), ncclAllGather on `hip_stream`.
+ *   rt_comm_gather      rank r's `send_bytes` bytes at `send` arrive on `root` at gathered + r * rank_stride_bytes.
+ *                       One grouped call: the root posts an ncclRecv of recv_bytes[r] bytes per rank (host array
+ *                       [n_ranks], read on the root only; it must name what each rank sends — both sides take the
+ *                       numbers from the count exchange), every rank an ncclSend of its own bytes, the root included
+ *                       (its share is a local copy inside RCCL) — n_ranks - 1 concurrent point-to-point transfers into
+ *                       the root, one per xGMI link, each of its own length: no padding to the largest rank travels.
+ *                       Ranks that have nothing to send post nothing.
+ * All device pointers; `hip_stream` is the caller's hipStream_t as void* (NULL = the context's stream of
+ * rt_set_stream): the calls are asynchronous on it and ordered with whatever else it holds. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int n_ranks, int rank);
+int rt_comm_destroy(rt_ctx* ctx);
+/* n_ranks / rank of the context's communicator (0 / -1 without one) and the RCCL version code bound (0: none yet). */
+int rt_comm_info(const rt_ctx* ctx, int* n_ranks, int* rank, int* rccl_version);
+int rt_comm_all_gather_counts(rt_ctx* ctx, const uint32_t* count_dev, uint32_t* counts_all_dev, void* hip_stream);
+int rt_comm_gather(rt_ctx* ctx, const void* send, int64_t send_bytes, void* gathered, const int64_t* recv_bytes,
+                   int64_t rank_stride_bytes, int root, void* hip_stream);
+
 /* Ray statistics accumulated by every render call since the last reset (device counters; this
  * call synchronises the stream).  out[0] = primary rays, out[1] = reflection rays,
  * out[2] = shadow rays, out[3] = shaded hits (compute_lighting calls).  A "ray" is one

@@ -14,6 +14,7 @@ _lib = None
 RT_RNG_CONSTANT, RT_RNG_KEYED = 0, 1
 FRAMES_PER_LAUNCH = 1024   # RT_FRAMES_PER_LAUNCH of include/rt355.h
 TILE_ENTRY_BYTES = 196     # RT_TILE_ENTRY_BYTES
+COMM_ID_BYTES = 128        # RT_COMM_ID_BYTES
 RT_OPT_KERNEL, RT_KERNEL_STREAM, RT_KERNEL_PIXEL = 1, 0, 1
 RT_OPT_OCCLUDER_TABLE = 2
 RT_OPT_QUEUE_SPILL = 4
@@ -26,7 +27,9 @@ RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT:
 SYMBOLS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize",
            "rt_set_option", "rt_upload_scene", "rt_set_refraction", "rt_set_cubes", "rt_occluder_table", "rt_reflect_table", "rt_render", "rt_render_noalloc", "rt_render_rows", "rt_render_frames_rows",
            "rt_render_chunk", "rt_render_frames",
-           "rt_scatter_rows", "rt_scatter_rows_frames", "rt_compact_tiles", "rt_place_tiles", "rt_get_ray_counts", "rt_reset_ray_counts", "rt_debug_counters", "rt_version")
+           "rt_scatter_rows", "rt_scatter_rows_frames", "rt_compact_tiles", "rt_place_tiles",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_counts", "rt_comm_gather",
+           "rt_get_ray_counts", "rt_reset_ray_counts", "rt_debug_counters", "rt_version")
 
 
 class RtError(RuntimeError):
@@ -84,6 +87,13 @@ def load():
     L.rt_compact_tiles.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int]
     L.rt_place_tiles.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                  ctypes.c_int64, c_void_p]
+    L.rt_comm_unique_id.argtypes = [c_void_p]
+    L.rt_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    L.rt_comm_destroy.argtypes = [c_void_p]
+    L.rt_comm_info.argtypes = [c_void_p, P(c_int), P(c_int), P(c_int)]
+    L.rt_comm_all_gather_counts.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+    L.rt_comm_gather.argtypes = [c_void_p, c_void_p, ctypes.c_int64, c_void_p, P(ctypes.c_int64), ctypes.c_int64, c_int,
+                                 c_void_p]
     L.rt_get_ray_counts.argtypes = [c_void_p, P(c_u64)]
     L.rt_reset_ray_counts.argtypes = [c_void_p]
     L.rt_debug_counters.argtypes = [c_void_p, P(c_u64)]

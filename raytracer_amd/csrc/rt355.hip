@@ -27,6 +27,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rt355.h"
@@ -154,6 +155,8 @@ struct rt_ctx {
     bool occ_valid = false;
   } last;
   DevLights lights{};
+  void* comm = nullptr;          // RCCL communicator of this context (rt_comm_init; rt_comm.hpp), one rank per process
+  int comm_ranks = 0, comm_rank = -1;
   std::string err;
 };
 
@@ -589,6 +592,8 @@ hipError_t allow_big_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
+#include "rt_comm.hpp"
+
 extern "C" {
 
 const char* rt_version(void) { return "rt355 0.2 (gfx950)"; }
@@ -666,6 +671,7 @@ int rt_create(int device_id, rt_ctx** out) {
 void rt_destroy(rt_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  if (ctx->comm) (void)rt_comm_destroy(ctx);
   if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
   if (ctx->d_geom) (void)hipFree(ctx->d_geom);
   if (ctx->d_mat) (void)hipFree(ctx->d_mat);

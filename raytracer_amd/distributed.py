@@ -3,10 +3,11 @@ animation batches (config 5).
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank renders tiles
 t = rank, rank+G, ... of the frame with the same keyed RNG, so the assembled image is byte-identical to a
-1-GPU render for scenes without refraction (refractive scenes sum tree nodes with float atomics: equal up to
-summation order, i.e. <= 1/255 on a few pixels, run to run as across GPU counts).  The only
-collective on the data path is a fixed-size ``gather`` to rank 0 — G-1 concurrent point-to-point transfers, one
-per xGMI link into GPU 0 — followed by the placement on the root.  The reference has no distributed code; its
+1-GPU render (refractive scenes included: their pixel sums are integers).  The only exchange on the
+data path is a ``gather`` to rank 0 — G-1 concurrent point-to-point transfers, one per xGMI link into GPU 0 —
+followed by the placement on the root.  With ``BatchExchange(comm=renderer)`` that gather and the count exchange
+before it run INSIDE librt355 (rt_comm_*: the library's own RCCL communicator, grouped ncclSend / ncclRecv of
+exactly the bytes each rank has); without it they go through torch.distributed's collectives.  The reference has no distributed code; its
 unused ``render_chunk`` tile split (raytracer.py:299-308) is the model.  Development boxes have one GPU: the RCCL
 path has run there as a group of ONE rank (``force_collectives``: every collective call of the N > 1 path, device
 tensors, the side stream — tests/test_gpu_rccl.py, bench.py with RT_BENCH_FORCE_EXCHANGE=1), several ranks only over
@@ -100,19 +101,32 @@ class BatchExchange:
     too, beside its own render (``place_tiles`` is called with the side stream current and must launch on it).  The
     render stream only waits, three batches later, for the gather that read the entry buffer it is about to overwrite.
     ``force_collectives``: a group of one rank still goes through every collective (the one-GPU rehearsal of this path).
+    ``comm``: a Renderer that holds a communicator (Renderer.comm_init): the two collectives of the sparse exchange are
+    then the library's (rt_comm_all_gather_counts, rt_comm_gather — every rank sends exactly its own entries, nothing is
+    padded to the largest rank), issued on the side stream; torch.distributed makes no call on the data path.
     """
 
     def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0, *,
                  compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, comm=None):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
+        self.comm = comm
+        if comm is not None:
+            info = comm.comm_info()
+            if compact is None or torch.device(device).type != "cuda":
+                raise ValueError("comm: the library's collectives serve the sparse exchange of device tensors")
+            if dist.is_initialized() and (info["n_ranks"], info["rank"]) != (self.world, self.rank):
+                raise ValueError(f"comm: the communicator is rank {info['rank']} of {info['n_ranks']}, "
+                                 f"the group rank {self.rank} of {self.world}")
+            self.world, self.rank = info["n_ranks"], info["rank"]
+        self.collectives = self.world > 1 or (force_collectives and (dist.is_initialized() or comm is not None))
         # device tensors over RCCL: the side-stream pipeline described above
-        self.on_side = self.collectives and torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl"
+        self.on_side = self.collectives and torch.device(device).type == "cuda" and \
+            (comm is not None or dist.get_backend(group) == "nccl")
         self.slabs = [torch.zeros((n_frames, slab_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
         self.sparse = compact is not None
         if self.sparse and (place_tiles is None or not capacity):
@@ -189,9 +203,17 @@ class BatchExchange:
             st["counts"] = self.count[b3]
         elif self.on_side:
             st["counts"] = self.counts_all[b3]
-            work = dist.all_gather_into_tensor(st["counts"], self.count[b3], group=self.group, async_op=True)
+            if self.comm is not None:
+                packed = torch.cuda.Event()
+                packed.record()                          # (render stream: this batch's compaction is queued)
+            else:
+                work = dist.all_gather_into_tensor(st["counts"], self.count[b3], group=self.group, async_op=True)
             with torch.cuda.stream(self.side):
-                work.wait()                              # the SIDE stream waits for the collective; the render stream goes on
+                if self.comm is not None:
+                    self.side.wait_event(packed)
+                    self.comm.comm_all_gather_counts(self.count[b3], st["counts"])   # ncclAllGather on the side stream
+                else:
+                    work.wait()                          # the SIDE stream waits for the collective; the render stream goes on
                 self.counts_host[b3].copy_(st["counts"], non_blocking=True)
                 st["ready"] = torch.cuda.Event()
                 st["ready"].record()
@@ -225,7 +247,7 @@ class BatchExchange:
         if max(counts) > self.capacity:
             raise RuntimeError(f"sparse exchange: {max(counts)} occupied tiles exceed the capacity of {self.capacity}")
         nmax = st["nmax"] = max(counts)
-        self.sent_bytes += nmax * self.entry_bytes + 4
+        self.sent_bytes += (counts[self.rank] if self.comm is not None else nmax) * self.entry_bytes + 4
         send = self.entries[st["b3"]][:max(nmax, 1)]
         dist, world = self.dist, self.world
         if not self.collectives:
@@ -234,8 +256,13 @@ class BatchExchange:
             with torch.cuda.stream(self.side):        # (RCCL's stream waits for the stream the call is made on)
                 if self.rank == self.dst:
                     st["gathered"] = torch.empty((world, max(nmax, 1), self.entry_bytes), dtype=torch.uint8, device=send.device)
-                st["work"] = dist.gather(send, list(st["gathered"].unbind(0)) if self.rank == self.dst else None,
-                                         dst=self.dst, group=self.group, async_op=True)
+                if self.comm is not None:             # grouped ncclSend / ncclRecv inside the library, on the side stream
+                    eb = self.entry_bytes
+                    self.comm.comm_gather(send, counts[self.rank] * eb, st["gathered"], [c * eb for c in counts],
+                                          max(nmax, 1) * eb, self.dst)
+                else:
+                    st["work"] = dist.gather(send, list(st["gathered"].unbind(0)) if self.rank == self.dst else None,
+                                             dst=self.dst, group=self.group, async_op=True)
         elif _staged(send, dist, self.group):
             host = send.cpu()
             parts = [torch.empty_like(host) for _ in range(world)] if self.rank == self.dst else None
@@ -256,7 +283,8 @@ class BatchExchange:
         if self.on_side:
             import torch
             with torch.cuda.stream(self.side):
-                st["work"].wait()
+                if st["work"] is not None:
+                    st["work"].wait()
                 if self.rank == self.dst:
                     self.place_tiles(st["gathered"], st["counts"], step)
                 # entries[b3] (read by the gather) and counts_all[b3] (read by the placement) may be written again after this

@@ -305,6 +305,54 @@ class Renderer:
                                            out.data_ptr()))
         return table
 
+    # -- RCCL behind the C ABI (rt_comm_*: the library's own communicator) -------------
+    def comm_init(self, group=None):
+        """Collective over the ranks of torch.distributed's ``group``: rank 0 makes RCCL's unique id (rt_comm_unique_id),
+        torch.distributed hands its 128 bytes round (plumbing: any channel would do), every rank joins
+        (rt_comm_init).  After this the exchange of BatchExchange(comm=renderer) runs inside librt355."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [None]
+        if rank == 0:
+            buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+            self._check(self._L.rt_comm_unique_id(buf))
+            box[0] = bytes(buf)
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+        self._check(self._L.rt_comm_init(self._h, ident, world, rank))
+
+    def comm_init_single(self):
+        """A communicator of ONE rank (no torch.distributed needed): the one-GPU rehearsal of the calls."""
+        buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+        self._check(self._L.rt_comm_unique_id(buf))
+        self._check(self._L.rt_comm_init(self._h, buf, 1, 0))
+
+    def comm_info(self) -> dict:
+        n, r, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._check(self._L.rt_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v)))
+        return dict(n_ranks=n.value, rank=r.value, rccl_version=v.value)
+
+    def comm_destroy(self):
+        self._check(self._L.rt_comm_destroy(self._h))
+
+    def comm_all_gather_counts(self, count, counts_all):
+        """counts_all[r] = rank r's count (device, 32-bit), on torch's CURRENT stream (rt_comm_all_gather_counts)."""
+        torch = _torch()
+        if count.numel() != 1 or count.element_size() != 4 or counts_all.element_size() != 4 or not counts_all.is_contiguous():
+            raise ValueError("count: one 32-bit word; counts_all: contiguous 32-bit [n_ranks]")
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._L.rt_comm_all_gather_counts(self._h, count.data_ptr(), counts_all.data_ptr(), ctypes.c_void_p(s)))
+
+    def comm_gather(self, send, send_bytes, gathered, recv_bytes, rank_stride_bytes, root=0):
+        """rt_comm_gather on torch's CURRENT stream: the first ``send_bytes`` bytes of ``send`` -> ``gathered`` (root
+        only; else None) at rank * rank_stride_bytes; ``recv_bytes``: what each rank sends (read on the root)."""
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        rb = (ctypes.c_int64 * len(recv_bytes))(*[int(b) for b in recv_bytes]) if recv_bytes is not None else None
+        self._check(self._L.rt_comm_gather(self._h, send.data_ptr(), int(send_bytes),
+                                           gathered.data_ptr() if gathered is not None else None, rb,
+                                           int(rank_stride_bytes), int(root), ctypes.c_void_p(s)))
+
     def ray_counts(self) -> dict:
         """{'primary','reflection','shadow','shaded_hits','total'} since the last reset (syncs)."""
         a = (ctypes.c_uint64 * 4)()

@@ -111,3 +111,102 @@ def test_rccl_group_of_one_runs_the_exchange():
     assert res["exchange"] == [True] * 7 and res["sent_bytes"] > 0
     assert res["gather_frames"] and res["dense_world1"]
     assert p.exitcode == 0
+
+
+def _worker_abi(q):
+    """The library's own communicator (rt_comm_*, include/rt355.h) as a group of ONE rank: no torch.distributed at all."""
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import torch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    res = {}
+    try:
+        from raytracer_amd import _lib, tiling
+        from raytracer_amd.distributed import BatchExchange
+        from raytracer_amd.render import Renderer
+        from raytracer_amd.scenes import generate_scene, orbit_camera
+        dev = "cuda:0"
+        L = _lib.load()
+        r = Renderer(0)
+        # ---- refusals before a communicator exists, and bad arguments
+        one = torch.tensor([41], dtype=torch.int32, device=dev)
+        every = torch.zeros(1, dtype=torch.int32, device=dev)
+        res["no_comm"] = (L.rt_comm_all_gather_counts(r._h, one.data_ptr(), every.data_ptr(), None) == -3 and
+                          L.rt_comm_gather(r._h, one.data_ptr(), 4, every.data_ptr(), (ctypes.c_int64 * 1)(4), 4, 0, None) == -3)
+        res["info_before"] = r.comm_info()
+        ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+        res["bad_init"] = (L.rt_comm_init(r._h, ident, 0, 0) == -1 and L.rt_comm_init(r._h, ident, 2, 2) == -1 and
+                           L.rt_comm_init(r._h, None, 1, 0) == -1 and L.rt_comm_unique_id(None) == -1)
+        # ---- the calls themselves
+        r.comm_init_single()
+        res["info"] = r.comm_info()
+        res["double_init"] = L.rt_comm_init(r._h, ident, 1, 0) == -3
+        r.comm_all_gather_counts(one, every)
+        send = torch.arange(7 * 196, dtype=torch.int32, device=dev).to(torch.uint8).view(7, 196)
+        gathered = torch.zeros((1, 9, 196), dtype=torch.uint8, device=dev)
+        r.comm_gather(send, 5 * 196, gathered, [5 * 196], 9 * 196, 0)          # 5 of the 7 entries travel
+        torch.cuda.synchronize()
+        res["all_gather_counts"] = int(every.item()) == 41
+        res["gather"] = bool(torch.equal(gathered[0, :5], send[:5])) and not bool(gathered[0, 5:].any())
+        res["bad_gather"] = (L.rt_comm_gather(r._h, send.data_ptr(), 196, gathered.data_ptr(), (ctypes.c_int64 * 1)(392), 9 * 196, 0, None) == -1 and
+                             L.rt_comm_gather(r._h, send.data_ptr(), 196, gathered.data_ptr(), (ctypes.c_int64 * 1)(196), 100, 0, None) == -1 and
+                             L.rt_comm_gather(r._h, send.data_ptr(), 196, gathered.data_ptr(), None, 196, 0, None) == -1 and
+                             L.rt_comm_gather(r._h, send.data_ptr(), 196, gathered.data_ptr(), (ctypes.c_int64 * 1)(196), 196, 1, None) == -1)
+        r.comm_gather(send, 0, gathered, [0], 9 * 196, 0)                        # nothing to send: nothing is posted
+        torch.cuda.synchronize()
+        # ---- the sparse exchange on the library's collectives (side-stream pipeline around real renders)
+        w, h, tr, F, steps = 320, 187, 8, 6, 7
+        r.upload_scene(generate_scene(8, 1, keep_default=True))
+        rows_max = tiling.max_local_rows(h, tr, 1)
+        frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device=dev)
+        kept = {}
+
+        def place_tiles(entries, counts, i):
+            r.place_tiles(entries, counts, w, h, tr, frames_out, on_current_stream=True)
+            kept[i] = frames_out.clone()
+
+        ex = BatchExchange(F, rows_max * w * 3, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
+                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), force_collectives=True, comm=r)
+        res["on_side"] = bool(ex.on_side) and ex.collectives
+        for i in range(steps):
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=ex.slab(i).view(F, rows_max, w, 3),
+                            tile_rows=tr, tile_first=0, tile_stride=1)
+            ex.submit(i)
+        ex.drain()
+        torch.cuda.synchronize()
+        ok = []
+        for i in range(steps):
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
+            ok.append(bool(torch.equal(kept[i], full)) and bool(full.any()))
+        res["exchange"] = ok
+        res["sent_bytes"] = int(ex.sent_bytes)
+        r.comm_destroy()
+        res["info_after"] = r.comm_info()
+        r.comm_init_single()          # a context may join again; rt_destroy releases what it still holds
+        r.close()
+    except Exception as e:      # noqa: BLE001  (reported to the parent)
+        res["error"] = repr(e)
+    finally:
+        q.put(res)
+
+
+def test_library_communicator_group_of_one():
+    """rt_comm_* through the C ABI on the GPU box: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / grouped
+    ncclSend + ncclRecv (to itself) / ncclCommDestroy inside librt355, bound to librccl at run time."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_abi, args=(q,))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert "error" not in res, res
+    assert res["no_comm"] and res["bad_init"] and res["double_init"] and res["bad_gather"], res
+    assert res["info_before"]["n_ranks"] == 0 and res["info_before"]["rank"] == -1
+    assert res["info"]["n_ranks"] == 1 and res["info"]["rank"] == 0 and res["info"]["rccl_version"] >= 20700, res["info"]
+    assert res["all_gather_counts"] and res["gather"], res
+    assert res["on_side"] and res["exchange"] == [True] * 7 and res["sent_bytes"] > 0, res
+    assert res["info_after"]["n_ranks"] == 0
+    assert p.exitcode == 0
