@@ -144,6 +144,14 @@ int rt_set_refraction(rt_ctx* ctx, const float* refraction, const float* refract
  * out_words: n * ceil(n/32) uint32. */
 int rt_occluder_table(const float* geom4, int n_spheres, const rt_lights* lights, uint32_t* out_words);
 
+/* The table as rt_upload_scene uploads it for scenes of fewer than 256 spheres (lists of the same rows from 256 on): one
+ * row per (sphere k, bucket of the unit surface normal at the shaded point) — the cube-map buckets of rt_reflect_table
+ * below, applied to the normal.  Bit c of row [k][bucket] is set if sphere c can be hit by some shadow ray that leaves
+ * a point of sphere k whose normal lies in the bucket; c = k itself only where such a ray can point back into the
+ * sphere (a point that faces both lights cannot be shadowed by its own sphere).  Most rows are empty.  Host-only, FP64,
+ * a conservative superset; exported for the brute-force test.  out_words: n * 6 dim^2 * ceil(n/32) uint32; 1 <= dim <= 16. */
+int rt_occluder_table_buckets(const float* geom4, int n_spheres, const rt_lights* lights, int dim, uint32_t* out_words);
+
 /* Host-only helper (needs no GPU, no context): the direction table rt_upload_scene builds for the reflection rays
  * of find_nearest_intersection (raytracer.py:152-172, called from trace_ray :246-248).  Directions are bucketed on
  * a cube map: face 2 m + (d[m] < 0) for the major axis m, cell (ix, iy) = floor((d[(m+1)%3] / |d[m]| + 1) dim / 2),

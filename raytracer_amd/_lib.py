@@ -25,7 +25,7 @@ RNG_MODES = {"C": RT_RNG_CONSTANT, "constant": RT_RNG_CONSTANT, RT_RNG_CONSTANT:
 
 #: every symbol include/rt355.h declares (tests check the .so exports all of them)
 SYMBOLS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize",
-           "rt_set_option", "rt_upload_scene", "rt_set_refraction", "rt_set_cubes", "rt_occluder_table", "rt_reflect_table", "rt_render", "rt_render_noalloc", "rt_render_rows", "rt_render_frames_rows",
+           "rt_set_option", "rt_upload_scene", "rt_set_refraction", "rt_set_cubes", "rt_occluder_table", "rt_occluder_table_buckets", "rt_reflect_table", "rt_render", "rt_render_noalloc", "rt_render_rows", "rt_render_frames_rows",
            "rt_render_chunk", "rt_render_frames",
            "rt_scatter_rows", "rt_scatter_rows_frames", "rt_compact_tiles", "rt_place_tiles",
            "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_counts", "rt_comm_gather",
@@ -65,6 +65,7 @@ def load():
     L.rt_upload_scene.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, P(RtLights)]
     L.rt_set_refraction.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.rt_occluder_table.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+    L.rt_occluder_table_buckets.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p]
     L.rt_reflect_table.argtypes = [c_void_p, c_int, c_int, c_void_p]
     L.rt_set_cubes.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]
     L.rt_render.argtypes = [c_void_p, P(RtCamera), c_int, c_int, c_int, c_int, c_int, c_u64,

@@ -124,7 +124,11 @@ struct rt_ctx {
   bool reflect_table = true;          // RT_OPT_REFLECT_TABLE
   int queue_spill = 1;                // RT_OPT_QUEUE_SPILL: 0 off, 1 automatic depth, 2.. = at most that many blocks per wave
   uint32_t* d_glass_bits = nullptr;   // bit c: sphere c has refraction > 0 (rt_set_refraction; zero after rt_upload_scene)
-  uint32_t* d_occl = nullptr;    // occluder table: [objects][ceil(n_spheres / 32)] (rt_upload_scene, rt_set_cubes)
+  uint32_t* d_occl = nullptr;    // occluder table: [objects][buckets of the normal][ceil(n_spheres / 32)] (upload_occluder_table; grown on demand)
+  size_t occl_bytes = 0;
+  int occl_dim = 0;              // buckets per cube-map face edge of the bit-mask rows (0: one row per object)
+  int occl_list_dim = 0;         // ... of the list rows (scenes with >= kGridFrom spheres)
+  size_t occl_start_bytes = 0;
   float4* d_cubes = nullptr;     // [n_cubes][2] min, max (rt_set_cubes); objects n_spheres.. of d_mat / d_spec / d_refr
   int n_cubes = 0;
   unsigned long long* d_counters = nullptr;
@@ -407,8 +411,8 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   p.n_spheres = ctx->n_spheres;
   p.geom = ctx->d_geom; p.mat = ctx->d_mat; p.spec = ctx->d_spec; p.refr = ctx->d_refr;
   p.cubes = ctx->d_cubes; p.n_cubes = ctx->n_cubes;
-  p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32;
-  p.occl_start = ctx->d_occl_start; p.occl_items = ctx->d_occl_items;
+  p.occl = ctx->d_occl; p.occl_words = (ctx->n_spheres + 31) / 32; p.occl_dim = ctx->occl_dim;
+  p.occl_start = ctx->d_occl_start; p.occl_items = ctx->d_occl_items; p.occl_list_dim = ctx->occl_list_dim;
   p.glass_bits = ctx->d_glass_bits;
   p.list_start = ctx->d_list_start; p.list_items = ctx->d_list_items;
   p.list_dim = (refr || cubes || !stream_kernel) ? 0 : ctx->list_dim;
@@ -563,6 +567,79 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
   return RT_OK;
 }
 
+// The occluder table of lighting()'s shadow scan for the context's spheres (ctx->h_geom, ctx->lights) and `n_boxes` boxes
+// behind them: bit-mask rows per (object, bucket of the surface normal) — boxes: every sphere, every bucket — and, from
+// kGridFrom spheres on, the same rows as lists for the list kernels.  Host build (FP64), one copy to the device.
+int upload_occluder_table(rt_ctx* ctx, int n_boxes) {
+  const int n = int(ctx->h_geom.size() / 4), words = (n + 31) / 32;
+  ctx->occl_dim = 0; ctx->occl_list_dim = 0;
+  if (n == 0) return RT_OK;
+  const float* geom4 = ctx->h_geom.data();
+  std::vector<uint32_t> object_rows;
+  build_occluder_table(geom4, n, ctx->lights, object_rows, ctx->occluder_table);
+  const int B = (ctx->occluder_table && n < kGridFrom) ? occluder_table_dim(n + n_boxes, n) : 0;
+  const int nb = B ? 6 * B * B : 1;
+  std::vector<uint32_t> rows;
+  if (B) build_occluder_buckets(geom4, n, ctx->lights, B, object_rows, rows);
+  else rows = object_rows;
+  rows.resize(size_t(n + n_boxes) * size_t(nb) * size_t(words), 0u);
+  for (size_t r = size_t(n) * size_t(nb); r < size_t(n + n_boxes) * size_t(nb); ++r)
+    for (int c = 0; c < n; ++c) rows[r * size_t(words) + size_t(c >> 5)] |= 1u << (c & 31);
+  const size_t bytes = rows.size() * sizeof(uint32_t);
+  if (bytes > ctx->occl_bytes) {
+    if (ctx->d_occl) (void)hipFree(ctx->d_occl);
+    ctx->d_occl = nullptr; ctx->occl_bytes = 0;
+    RT_HIP(ctx, hipMalloc(&ctx->d_occl, bytes));
+    ctx->occl_bytes = bytes;
+  }
+  RT_HIP(ctx, hipMemcpy(ctx->d_occl, rows.data(), bytes, hipMemcpyHostToDevice));
+  ctx->occl_dim = B;
+  if (n >= kGridFrom && n_boxes == 0) {   // the list kernels (sphere-only scenes) read rows as lists (lighting<..., LIST>)
+    const int LB = ctx->occluder_table ? occluder_table_dim(n, n) : 0, lnb = LB ? 6 * LB * LB : 1;
+    std::vector<uint32_t> brows;
+    if (LB) build_occluder_buckets(geom4, n, ctx->lights, LB, object_rows, brows);
+    const std::vector<uint32_t>& src = LB ? brows : object_rows;
+    std::vector<uint32_t> start(size_t(n) * size_t(lnb) + 1, 0u);
+    std::vector<uint2> items;
+    for (size_t r = 0; r < size_t(n) * size_t(lnb); ++r) {
+      start[r] = uint32_t(items.size());
+      uint32_t v[4];
+      int fill = 0;
+      for (int w = 0; w < words; ++w) {
+        uint32_t bits = src[r * size_t(words) + size_t(w)];
+        while (bits) {
+          v[fill++] = uint32_t(32 * w + __builtin_ctz(bits));
+          bits &= bits - 1u;
+          if (fill == 4) { items.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16))); fill = 0; }
+        }
+      }
+      if (fill) {
+        for (int q = fill; q < 4; ++q) v[q] = 0xFFFFu;
+        items.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16)));
+      }
+    }
+    start.back() = uint32_t(items.size());
+    items.push_back(make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
+    const size_t sb = start.size() * sizeof(uint32_t), ib = items.size() * sizeof(uint2);
+    if (sb > ctx->occl_start_bytes) {
+      if (ctx->d_occl_start) (void)hipFree(ctx->d_occl_start);
+      ctx->d_occl_start = nullptr; ctx->occl_start_bytes = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_occl_start, sb));
+      ctx->occl_start_bytes = sb;
+    }
+    if (ib > ctx->occl_items_bytes) {
+      if (ctx->d_occl_items) (void)hipFree(ctx->d_occl_items);
+      ctx->d_occl_items = nullptr; ctx->occl_items_bytes = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_occl_items, ib));
+      ctx->occl_items_bytes = ib;
+    }
+    RT_HIP(ctx, hipMemcpy(ctx->d_occl_start, start.data(), sb, hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_occl_items, items.data(), ib, hipMemcpyHostToDevice));
+    ctx->occl_list_dim = LB;
+  }
+  return RT_OK;
+}
+
 // The direction table of secondary rays (bit-mask form, scenes of 4 .. 255 spheres) for the context's spheres and `n_boxes`
 // boxes: built on the host, copied to the device (the buffer grows on demand).
 int upload_reflect_table(rt_ctx* ctx, const float4* boxes, int n_boxes) {
@@ -644,9 +721,6 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_spec, sizeof(float) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_refr, sizeof(float2) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_cubes, sizeof(float4) * RT_MAX_SPHERES)) != hipSuccess) return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_occl, sizeof(uint32_t) * RT_MAX_SPHERES * (RT_MAX_SPHERES / 32))) != hipSuccess)
-    return bail(e, "hipMalloc");
-  if ((e = hipMalloc(&ctx->d_occl_start, sizeof(uint32_t) * (RT_MAX_SPHERES + 1))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMalloc(&ctx->d_glass_bits, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMalloc(&ctx->d_frames, sizeof(FrameRec) * kMaxBatch)) != hipSuccess) return bail(e, "hipMalloc");
@@ -785,41 +859,8 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   L.aint = lights->area_intensity; L.ns = lights->area_samples; L.inv_ns = 1.0f / float(L.ns);
   L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
                    std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
-  if (n_spheres > 0) {
-    std::vector<uint32_t> occl;
-    build_occluder_table(geom4, n_spheres, L, occl, ctx->occluder_table);
-    RT_HIP(ctx, hipMemcpy(ctx->d_occl, occl.data(), sizeof(uint32_t) * occl.size(), hipMemcpyHostToDevice));
-    if (n_spheres >= kGridFrom) {   // the GRID kernels read the rows as lists (lighting<..., LIST>)
-      const int words = (n_spheres + 31) / 32;
-      std::vector<uint32_t> start(size_t(n_spheres) + 1, 0u);
-      std::vector<uint2> items;
-      for (int k = 0; k < n_spheres; ++k) {
-        start[size_t(k)] = uint32_t(items.size());
-        uint32_t v[4];
-        int fill = 0;
-        for (int c = 0; c < n_spheres; ++c)
-          if ((occl[size_t(k) * size_t(words) + size_t(c >> 5)] >> (c & 31)) & 1u) {
-            v[fill++] = uint32_t(c);
-            if (fill == 4) { items.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16))); fill = 0; }
-          }
-        if (fill) {
-          for (int q = fill; q < 4; ++q) v[q] = 0xFFFFu;
-          items.push_back(make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16)));
-        }
-      }
-      start[size_t(n_spheres)] = uint32_t(items.size());
-      items.push_back(make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
-      const size_t ib = items.size() * sizeof(uint2);
-      if (ib > ctx->occl_items_bytes) {
-        if (ctx->d_occl_items) (void)hipFree(ctx->d_occl_items);
-        ctx->d_occl_items = nullptr; ctx->occl_items_bytes = 0;
-        RT_HIP(ctx, hipMalloc(&ctx->d_occl_items, ib));
-        ctx->occl_items_bytes = ib;
-      }
-      RT_HIP(ctx, hipMemcpy(ctx->d_occl_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      RT_HIP(ctx, hipMemcpy(ctx->d_occl_items, items.data(), ib, hipMemcpyHostToDevice));
-    }
-  }
+  ctx->h_geom.assign(geom4, geom4 + size_t(4) * size_t(n_spheres));   // (rt_set_cubes builds the tables again, with the boxes)
+  if (int rc = upload_occluder_table(ctx, 0)) return rc;
   ctx->list_dim = 0;
   if (ctx->reflect_table && n_spheres >= kGridFrom) {   // many spheres: the direction table as lists
     std::vector<uint32_t> start;
@@ -843,7 +884,6 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
       ctx->list_dim = kReflListDim;
     }
   }
-  ctx->h_geom.assign(geom4, geom4 + size_t(4) * size_t(n_spheres));   // (rt_set_cubes builds the table again, with the boxes)
   if (int rc = upload_reflect_table(ctx, nullptr, 0)) return rc;
   RT_HIP(ctx, hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32)));
   {   // can a node of a pixel's tree contribute a negative share?  (see rt_ctx::sums_never_negative)
@@ -894,15 +934,8 @@ int rt_set_cubes(rt_ctx* ctx, const float* box6, const float* mat4, const float*
     RT_HIP(ctx, hipMemcpy(ctx->d_mat + at, mat4, sizeof(float4) * size_t(n_cubes), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_spec + at, spec, sizeof(float) * size_t(n_cubes), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_refr + at, rf.data(), sizeof(float2) * size_t(n_cubes), hipMemcpyHostToDevice));
-    // occluder table rows of the cubes: every sphere may shadow a point of a box
-    const int words = (ctx->n_spheres + 31) / 32;
-    if (words > 0) {
-      std::vector<uint32_t> rows(size_t(n_cubes) * size_t(words), 0u);
-      for (int i = 0; i < n_cubes; ++i)
-        for (int c = 0; c < ctx->n_spheres; ++c) rows[size_t(i) * size_t(words) + size_t(c >> 5)] |= 1u << (c & 31);
-      RT_HIP(ctx, hipMemcpy(ctx->d_occl + at * size_t(words), rows.data(), sizeof(uint32_t) * rows.size(),
-                            hipMemcpyHostToDevice));
-    }
+    // occluder table rows of the cubes (every sphere may shadow a point of a box), behind the spheres' rows
+    if (int rc = upload_occluder_table(ctx, n_cubes)) return rc;
   }
   ctx->n_cubes = 0;
   // secondary rays of a scene with boxes: the direction table again, with the boxes as sources and targets
@@ -925,6 +958,21 @@ int rt_occluder_table(const float* geom4, int n_spheres, const rt_lights* lights
   build_occluder_table(geom4, n_spheres, L, tab);
   const size_t words = size_t(n_spheres) * size_t((n_spheres + 31) / 32);
   if (words) memcpy(out_words, tab.data(), words * sizeof(uint32_t));
+  return RT_OK;
+}
+
+int rt_occluder_table_buckets(const float* geom4, int n_spheres, const rt_lights* lights, int dim, uint32_t* out_words) {
+  if (n_spheres < 1 || n_spheres > RT_MAX_SPHERES || !lights || !out_words || !geom4 || dim < 1 || dim > 16)
+    return fail(nullptr, RT_EINVAL, "rt_occluder_table_buckets: bad argument");
+  DevLights L{};
+  memcpy(L.ppos, lights->point_pos, 12);
+  memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
+  L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
+                   std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
+  std::vector<uint32_t> object_rows, tab;
+  build_occluder_table(geom4, n_spheres, L, object_rows);
+  build_occluder_buckets(geom4, n_spheres, L, dim, object_rows, tab);
+  memcpy(out_words, tab.data(), tab.size() * sizeof(uint32_t));
   return RT_OK;
 }
 

@@ -66,6 +66,8 @@ struct RenderParams {
   const uint32_t* glass_bits;  // [ceil(n_spheres / 32)] bit c: sphere c is refractive (REFR kernels' shadow scan)
   const uint32_t* occl;  // [objects][occl_words] bit c of row k: sphere c can shadow some point of object k (host table)
   int occl_words;        // ceil(n_spheres / 32)
+  int occl_dim;          // > 0: rows per (object, bucket of the surface normal): row (k * 6 dim^2 + direction_bucket(N, dim)); 0: row k
+  int occl_list_dim;     // the same for the list rows (occl_start)
   // the same table as lists, for scenes with many spheres (the GRID kernels; 32 .. 64 mostly empty words per row otherwise):
   // row k is the run of 4-index chunks occl_start[k] .. occl_start[k + 1] of occl_items (uint16, ascending, padded with 0xFFFF)
   const uint32_t* occl_start;
@@ -124,6 +126,9 @@ struct RenderParams {
 #define RT_VIS_WAVES 5     // its __launch_bounds__ occupancy target (waves per SIMD); 8 with 3+ tiles spills
 #endif
 constexpr int kVisTiles = RT_VIS_TILES;
+#ifndef RT_VIS_REGION_BLOCKS
+#define RT_VIS_REGION_BLOCKS 1   // the region culls the scene against the cones of all its blocks at once (scenes of up to 64 spheres)
+#endif
 #ifndef RT_VIS_SKIP
 #define RT_VIS_SKIP 1      // the visibility pass culls per wave at any sphere count: blocks that no sphere reaches build no rays
 #endif
@@ -249,6 +254,13 @@ __device__ __forceinline__ bool tile_rows_uniform(const RenderParams& p) {
 __device__ __forceinline__ int tile_row_base(const RenderParams& p, int row0) {
   if (p.tile_stride == 1) return p.y0 + p.tile_first * p.tile_rows + row0;   // contiguous rows
   const int j = row0 / p.tile_rows;                                          // scalar division
+  return p.y0 + (p.tile_first + j * p.tile_stride) * p.tile_rows + (row0 - j * p.tile_rows);
+}
+
+// (the same with a row0 of the lane's own: a vector division where the rows are not contiguous)
+__device__ __forceinline__ int tile_row_base_lane(const RenderParams& p, int row0) {
+  if (p.tile_stride == 1) return p.y0 + p.tile_first * p.tile_rows + row0;
+  const int j = row0 / p.tile_rows;
   return p.y0 + (p.tile_first + j * p.tile_stride) * p.tile_rows + (row0 - j * p.tile_rows);
 }
 
@@ -425,6 +437,11 @@ __device__ __forceinline__ int direction_bucket(float dx, float dy, float dz, in
   const int ix = min(B - 1, max(0, int(fmaf(a * inv, hB, hB))));
   const int iy = min(B - 1, max(0, int(fmaf(b * inv, hB, hB))));
   return ((2 * m + (major < 0.0f ? 1 : 0)) * B + iy) * B + ix;
+}
+// Row of the occluder table (bit masks: `dim` = p.occl_dim; lists: p.occl_list_dim) for a hit on object `idx` whose
+// unit surface normal is N: rows are kept per bucket of the normal (build_occluder_buckets), or per object (dim = 0).
+__device__ __forceinline__ size_t occluder_row(int dim, int idx, float nx, float ny, float nz) {
+  return dim > 0 ? size_t(idx) * size_t(6 * dim * dim) + size_t(direction_bucket(nx, ny, nz, dim)) : size_t(idx);
 }
 template <bool CUBES = false>
 __device__ __forceinline__ void nearest_table(const RenderParams& p, const float4* __restrict__ sg, int obj, float ox,

@@ -456,7 +456,8 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
   const LightSums w = lighting<MODE, (CUBES ? kCubeShadowBatch : kShadowBatch), false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr,
-                               LIST ? p.occl_start + idx : p.occl + size_t(idx) * size_t(p.occl_words), p.occl_items, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
+                               LIST ? p.occl_start + occluder_row(p.occl_list_dim, idx, nx, ny, nz)
+                                    : p.occl + occluder_row(p.occl_dim, idx, nx, ny, nz) * size_t(p.occl_words), p.occl_items, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
                                level_key);
   float4 m;
   float spec;

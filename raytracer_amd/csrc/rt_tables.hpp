@@ -215,3 +215,78 @@ void build_occluder_table(const float* geom4, int n, const DevLights& L, std::ve
       for (int c = 0; c < n; ++c) row[c >> 5] |= 1u << (c & 31);
   }
 }
+
+// The same question per (object, BUCKET OF THE SURFACE NORMAL at the shaded point) — direction_bucket() of the unit
+// normal, the cube map of the direction table.  A hit on sphere k whose normal lies in bucket b (axis a, half-angle h)
+// has its shadow origin S = P + 0.001 N within chord(h) (r_k + 0.001) of Q = K + (r_k + 0.001) a: the ball (Q, rho_b)
+// takes the place of the whole sphere's ball (K, rho) above, and far fewer spheres reach into the much narrower cone of
+// its rays.  Sphere k ITSELF is a candidate only where some ray of the bucket can point back into it: a ray that leaves
+// S with N . u >= 0 moves away from K for good, and N . u >= cos(h + angle(a, A - Q) + asin((rho_b + R) / |A - Q|)).
+// Most shaded points face their lights and are shadowed by nothing: their rows are EMPTY, and a pass of such points
+// skips the candidate loops of lighting() altogether (the object-level rows always held the sphere itself).
+// Rows [k][6 B^2][ceil(n / 32)]; candidates are drawn from the object-level row (a superset), so the build is
+// n x 6 B^2 x (a few) cone tests.  Margins: `h` carries 1e-3 rad for the kernel's FP32 bucket arithmetic
+// (direction_patches) plus the FP32 error of the normal itself, ~|P| ulp / r_k.
+int occluder_table_dim(int n_objects, int n_spheres) {
+  if (n_spheres < 1) return 0;
+  if (n_spheres >= kGridFrom) return 8;                      // (lists: 384 entries per object)
+  const size_t words = size_t((n_spheres + 31) / 32);
+  for (int B : {16, 8, 4}) if (size_t(n_objects) * size_t(6 * B * B) * words * 4 <= (size_t(4) << 20)) return B;
+  return 0;
+}
+void build_occluder_buckets(const float* geom4, int n, const DevLights& L, int B, const std::vector<uint32_t>& object_rows,
+                            std::vector<uint32_t>& tab) {
+  const int words = (n + 31) / 32, nb = 6 * B * B;
+  const double kHalfPi = 1.57079632679489661923;
+  tab.assign(size_t(n) * size_t(nb) * size_t(words), 0u);
+  const std::vector<DirPatch> patch = direction_patches(B);
+  struct Ball { double x, y, z, r; };
+  const Ball lights[2] = {{L.ppos[0], L.ppos[1], L.ppos[2], 1e-4},
+                          {L.apos[0], L.apos[1], L.apos[2], double(L.arad) * 1.001 + 1e-4}};
+  std::vector<int> cand;
+  for (int k = 0; k < n; ++k) {
+    const double kx = geom4[4 * k], ky = geom4[4 * k + 1], kz = geom4[4 * k + 2];
+    const double rk = std::sqrt(double(geom4[4 * k + 3]));
+    const double reach = std::fabs(kx) + std::fabs(ky) + std::fabs(kz) + rk;          // >= |P| for every point of the sphere
+    const uint32_t* orow = object_rows.data() + size_t(k) * size_t(words);
+    cand.clear();
+    for (int c = 0; c < n; ++c) if ((orow[c >> 5] >> (c & 31)) & 1u) cand.push_back(c);
+    // (a sphere too small for its normals to mean anything in FP32 keeps the object-level row in every bucket)
+    const double h_extra = rk > 0.0 ? 1e-6 * reach / rk : 10.0;
+    for (int b = 0; b < nb; ++b) {
+      uint32_t* row = tab.data() + (size_t(k) * size_t(nb) + size_t(b)) * size_t(words);
+      const DirPatch& P = patch[size_t(b)];
+      const double hh = P.h + h_extra;
+      bool all = !(hh < 1.0);
+      const double rho = 2.0 * (rk + 0.001) * std::sin(0.5 * std::min(hh, 1.0)) * 1.001 + 1e-3 + 1e-6 * reach;
+      const double qx = kx + (rk + 0.001) * P.x, qy = ky + (rk + 0.001) * P.y, qz = kz + (rk + 0.001) * P.z;
+      for (const Ball& A : lights) {
+        if (all) break;
+        const double ax = A.x - qx, ay = A.y - qy, az = A.z - qz;
+        const double d = std::sqrt(ax * ax + ay * ay + az * az);
+        if (!(d > (rho + A.r) * 1.01)) { all = true; break; }
+        const double ux = ax / d, uy = ay / d, uz = az / d;
+        const double sn = (rho + A.r) / d, cs = std::sqrt(1.0 - sn * sn);
+        const double back = rho / sn;
+        const double px = qx - ux * back, py = qy - uy * back, pz = qz - uz * back;
+        for (int c : cand) {
+          if (c == k) {
+            // can a ray of this bucket point back into the sphere it leaves?  (see above; the floor on the cosine keeps the
+            // sign of the kernel's FP32 `nb` = (K - S) . u, whose magnitude is (r_k + 0.001) N . u, out of rounding's reach)
+            const double phi = hh + std::acos(std::max(-1.0, std::min(1.0, P.x * ux + P.y * uy + P.z * uz))) + std::asin(sn);
+            const double floor_cos = std::max(1e-3, 1e-5 * (reach + 1.0) / (rk + 0.001));
+            if (!(phi < kHalfPi && std::cos(phi) >= floor_cos)) row[c >> 5] |= 1u << (c & 31);
+            continue;
+          }
+          const double cx = geom4[4 * c] - px, cy = geom4[4 * c + 1] - py, cz = geom4[4 * c + 2] - pz;
+          const double d2 = cx * cx + cy * cy + cz * cz;
+          const double along = cx * ux + cy * uy + cz * uz;
+          const double perp = std::sqrt(std::max(0.0, d2 - along * along));
+          const double rc = std::sqrt(double(geom4[4 * c + 3]));
+          if (perp * cs - along * sn <= rc * 1.001 + 1e-3 * (1.0 + std::sqrt(d2))) row[c >> 5] |= 1u << (c & 31);
+        }
+      }
+      if (all) for (int w = 0; w < words; ++w) row[w] = orow[w];
+    }
+  }
+}

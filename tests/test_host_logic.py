@@ -184,6 +184,74 @@ def test_occluder_table_is_a_superset_of_brute_force():
             assert bits.sum(1).mean() < 0.25 * n
 
 
+def _bucket_f32(Df, B):
+    """direction_bucket() of rt_core.hpp, in FP32 as the kernel computes it."""
+    m = len(Df)
+    a = np.abs(Df); mx = (a[:, 0] >= a[:, 1]) & (a[:, 0] >= a[:, 2]); my = ~mx & (a[:, 1] >= a[:, 2])
+    mi = np.where(mx, 0, np.where(my, 1, 2)); idx = np.arange(m)
+    major = Df[idx, mi]; inv = np.float32(1.0) / np.abs(major)
+    hB = np.float32(0.5 * B)
+    ix = np.clip((Df[idx, (mi + 1) % 3] * inv * hB + hB).astype(np.int32), 0, B - 1)
+    iy = np.clip((Df[idx, (mi + 2) % 3] * inv * hB + hB).astype(np.int32), 0, B - 1)
+    return ((2 * mi + (major < 0)) * B + iy) * B + ix
+
+
+def test_occluder_buckets_are_a_superset_of_brute_force():
+    """rt_occluder_table_buckets (host-only, FP64): rows per (sphere k, bucket of the surface normal).  Brute force:
+    random points on each sphere (normal N, shadow origin 0.001 along it, raytracer.py:184, :199), rays to the point
+    light and to corners / random points of the area light, intersect_sphere (:93-104) against EVERY sphere, k itself
+    included: whatever is hit must be listed in the row of (k, bucket of N) — the bucket computed in FP32 as the kernel
+    does.  Also: the rows are far emptier than the per-object rows, and points that face both lights list nothing."""
+    import ctypes
+    from raytracer_amd import _lib
+    from raytracer_amd.scenes import AreaLight, Light, Vector3, generate_scene, pack_scene, default_scene
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    near = generate_scene(20, 5)        # lights next to and inside spheres: the "rays go anywhere" rows
+    s0 = near["spheres"][0]
+    near["global_light"] = Light(Vector3(s0.center.x + s0.radius * 1.02, s0.center.y, s0.center.z), Vector3(1, 1, 1), 0.9)
+    near["area_light"] = AreaLight(Vector3(near["spheres"][3].center.x, near["spheres"][3].center.y, near["spheres"][3].center.z),
+                                   Vector3(3, 0, 0), Vector3(0, 2, 1), Vector3(1, 1, 1), 0.9, samples=12)
+    for scene, B in ((default_scene(), 16), (generate_scene(8, 1, keep_default=True), 16), (generate_scene(64, 2), 16),
+                     (generate_scene(64, 2), 4), (generate_scene(150, 7), 8), (near, 8)):
+        p = pack_scene(scene)
+        n, words, nb = p.n_spheres, (p.n_spheres + 31) // 32, 6 * B * B
+        out = np.zeros((n, nb, words), np.uint32)
+        lights = p.ct_lights()
+        g = np.ascontiguousarray(p.geom4, np.float32)
+        assert L.rt_occluder_table_buckets(g.ctypes.data, n, ctypes.byref(lights), B, out.ctypes.data) == 0
+        bits = ((out[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, nb, -1)[:, :, :n].astype(bool)
+        obj = np.zeros((n, words), np.uint32)
+        assert L.rt_occluder_table(g.ctypes.data, n, ctypes.byref(lights), obj.ctypes.data) == 0
+        obits = ((obj[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)[:, :n].astype(bool)
+        assert not (bits & ~obits[:, None, :]).any()                   # a refinement of the per-object rows
+        C = p.geom4[:, :3].astype(np.float64); r = np.sqrt(p.geom4[:, 3].astype(np.float64))
+        lv = p.lights.astype(np.float64)
+        ppos, apos, au, av = lv[0:3], lv[7:10], lv[10:13], lv[13:16]
+        targets = [ppos] + [apos + au * a + av * b for a in (-0.5, 0.5) for b in (-0.5, 0.5)] + \
+                  [apos + au * (rng.random() - 0.5) + av * (rng.random() - 0.5) for _ in range(6)]
+        missing = 0
+        for k in range(n):
+            m = 1500
+            nrm = rng.normal(size=(m, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            S = C[k] + nrm * (r[k] + 0.001)
+            bucket = _bucket_f32(nrm.astype(np.float32), B)
+            for T in targets:
+                Ld = T - S; Ld /= np.linalg.norm(Ld, axis=1, keepdims=True)
+                oc = S[:, None, :] - C[None, :, :]
+                b = 2 * np.einsum("psk,pk->ps", oc, Ld)
+                c = np.einsum("psk,psk->ps", oc, oc) - r[None, :] ** 2
+                disc = b * b - 4 * c
+                t = (-b - np.sqrt(np.maximum(disc, 0))) / 2
+                hit = (disc >= 0) & (t > 0)
+                missing += int((hit & ~bits[k, bucket]).sum())
+        assert missing == 0, "a sphere that a shadow ray hits is missing from the row of its (object, normal bucket)"
+        if scene is not near and B >= 8:
+            print(n, B, bits.sum(2).mean(), obits.sum(1).mean(), (bits.sum(2) == 0).mean())
+            assert bits.sum(2).mean() < 0.6 * obits.sum(1).mean()      # emptier than the per-object rows
+            assert (bits.sum(2) == 0).mean() > 0.15                    # and a good share of the rows lists nothing at all
+
+
 def test_reflect_table_is_a_superset_of_brute_force():
     """rt_reflect_table (host-only, FP64): bit j of entry [k][bucket] must be set for every ray that leaves sphere k
     (random surface points, offset 0.001 along the normal, raytracer.py:247; random outward directions — every
