@@ -165,11 +165,11 @@ constexpr int kReferenceShadowRays = 13;
 #define RT_CUBE_BATCH 7
 #endif
 #ifndef RT_REFR_CUBE_BATCH
-#define RT_REFR_CUBE_BATCH 5
+#define RT_REFR_CUBE_BATCH 7     // (5 until both verdicts of a ray shared one register: 266 -> 287 Grays/s on cube_scene(glass); 9: 254, 13: 182)
 #endif
 constexpr int kCubeShadowBatch = RT_CUBE_BATCH;            // scenes with boxes
 constexpr int kRefrCubeShadowBatch = RT_REFR_CUBE_BATCH;   // ... and refractive materials
-constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: two verdicts per ray (opaque / glass), so fewer rays per batch fit the registers
+constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: the tree's two children are formed behind lighting(), so fewer rays per batch fit the registers (7: 456 Grays/s on refractive_scene(), 9: 420, 10: 401, 13: 437)
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
 constexpr int kTileW = 32, kTileH = 8;

@@ -77,9 +77,11 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
   [[maybe_unused]] uint32_t kept0 = 0u, kept1 = 0u, keptc = 0u;
   for (int base = 0; base < nrays; base += B) {
     float Lx[B], Ly[B], Lz[B], m[B];
-    float mrf[REFR ? B : 1];   // REFR: the same verdicts for the REFRACTIVE spheres (m: the opaque ones)
-#pragma unroll
-    for (int k = 0; k < (REFR ? B : 1); ++k) mrf[k] = -1.0f;
+    // REFR: a ray has TWO running verdicts — "no opaque object hit yet" in the sign bit of m[k], "no refractive one hit yet" in
+    // its bit 0 (one register per ray, as in the opaque kernels: a second array of verdicts cost B registers, and with them
+    // the single batch of 13 rays).  A candidate's verdict word is rotated onto the bit of its class (v_alignbit by a
+    // per-lane amount) and every other bit is kept: m &= rot(verdict) | keep.
+    constexpr uint32_t kNoHitYet = REFR ? 0x80000001u : 0xBF800000u;     // (0xBF800000 = -1.0f: the opaque kernels' "sign set")
 #pragma unroll
     for (int k = 0; k < B; ++k) {
       const int j = base + k;
@@ -97,7 +99,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       // weight below (N.L, V.R) is then 0 too
       const float inv = (j < nrays) ? frsq(fmaf(lz, lz, fmaf(ly, ly, lx * lx))) : 0.0f;
       Lx[k] = lx * inv; Ly[k] = ly * inv; Lz[k] = lz * inv;
-      m[k] = -1.0f;   // sign bit set = "no sphere hit yet" in both accumulation forms
+      m[k] = __uint_as_float(kNoHitYet);   // sign bit set = "no sphere hit yet" in both accumulation forms
     }
     // One sphere against the B rays.  Verdict accumulation: with RT_ACC_BITS the sign bits do the
     // work at full VALU rate — hit <=> sign(dl) == 0 and sign(nb) == 0, so `acc &= (dl | nb)`
@@ -118,14 +120,16 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
       const float chi = (c > 0.0f) ? c + thr : INFINITY;   // origin inside the sphere: never hit
       const float thr2 = thr + thr;
       uint32_t amb = 0u;
+      [[maybe_unused]] const uint32_t rot = (glass >> 31) * 31u;                          // refractive: sign bit -> bit 0
+      [[maybe_unused]] const uint32_t keep = 0x7FFFFFFFu ^ ((glass >> 31) * 0x80000001u);  // every bit but the class's own
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const float nb = fmaf(cz, Lz[k], fmaf(cy, Ly[k], cx * Lx[k]));
         const float dh = fmaf(nb, nb, -chi);
         const float dlo = dh + thr2;
         const uint32_t verdict = __float_as_uint(dh) | __float_as_uint(nb);
-        m[k] = __uint_as_float(__float_as_uint(m[k]) & (REFR ? verdict | glass : verdict));
-        if constexpr (REFR) mrf[k] = __uint_as_float(__float_as_uint(mrf[k]) & (verdict | (glass ^ 0x80000000u)));
+        if constexpr (REFR) m[k] = __uint_as_float(__float_as_uint(m[k]) & (__builtin_amdgcn_alignbit(verdict, verdict, rot) | keep));
+        else m[k] = __uint_as_float(__float_as_uint(m[k]) & verdict);
         amb |= __float_as_uint(dh) & ~__float_as_uint(dlo);   // sign set: dh < 0 <= dh + 2 thr
         asm volatile("" : "+v"(m[k]), "+v"(amb));   // keep both chains sequential (no reassociation tree)
       }
@@ -138,8 +142,8 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
           const float lx = fmaf(-nb, Lx[k], cx), ly = fmaf(-nb, Ly[k], cy), lz = fmaf(-nb, Lz[k], cz);
           const float dl = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
           const uint32_t verdict = __float_as_uint(dl) | __float_as_uint(nb);
-          m[k] = __uint_as_float(__float_as_uint(m[k]) & (REFR ? verdict | glass : verdict));
-          if constexpr (REFR) mrf[k] = __uint_as_float(__float_as_uint(mrf[k]) & (verdict | (glass ^ 0x80000000u)));
+          if constexpr (REFR) m[k] = __uint_as_float(__float_as_uint(m[k]) & (__builtin_amdgcn_alignbit(verdict, verdict, rot) | keep));
+          else m[k] = __uint_as_float(__float_as_uint(m[k]) & verdict);
           asm volatile("" : "+v"(m[k]));   // keep the and-chain sequential (no reassociation tree)
         }
       }
@@ -338,7 +342,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
                           b2 = fmaf(hx, fabsf(ly), hy * fabsf(lx));
               if (fabsf(c0) <= b0 && fabsf(c1) <= b1 && fabsf(c2) <= b2) {
                 if constexpr (REFR) {                              // (which kind of hit: see below)
-                  if (glass_cube) mrf[k] = 0.0f; else m[k] = 0.0f;
+                  m[k] = __uint_as_float(__float_as_uint(m[k]) & (glass_cube ? 0xFFFFFFFEu : 0x7FFFFFFFu));
                 } else {
                   m[k] = 0.0f;
                 }
@@ -350,27 +354,26 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
     }
     if constexpr (REFR) {
       // Scenes with refractive materials: a shadow ray is blocked only if its NEAREST hit is opaque
-      // (raytracer.py:187, :202).  The scan above has told, per ray, whether it hits SOME opaque sphere (m) and
-      // whether it hits SOME refractive one (mrf) — the any-hit tests of the opaque path, over the same culled
+      // (raytracer.py:187, :202).  The scan above has told, per ray, whether it hits SOME opaque object (sign of m[k] clear)
+      // and whether it hits SOME refractive one (bit 0 clear) — the any-hit tests of the opaque path, over the same culled
       // candidates, no root taken.  No opaque hit: lit.  Opaque hits only: blocked.  Both (a ray through glass
       // towards something solid, or the other way round: rare): the nearest hit decides, found by the full scan
-      // of find_nearest_intersection for that ray.  Cubes (their line rule, :137, :162) have been entered into m and mrf above.
-      // (sign bits as truth values, as in the scan: m / mrf have their sign CLEAR where an opaque / a refractive object was
-      // hit; lit <=> no opaque hit or some refractive one <=> sign of m | ~mrf set: two operations per ray.  Whether any ray
-      // of the lane was hit by objects of BOTH kinds — sign of m | mrf clear — is asked once per batch.)
+      // of find_nearest_intersection for that ray.  Cubes (their line rule, :137, :162) have entered their verdicts above.
+      // (lit <=> no opaque hit or some refractive one <=> sign of w | ~(w << 31) set; whether any ray of the lane was hit
+      // by objects of BOTH kinds — sign of w | (w << 31) clear — is asked once per batch.)
+      // (m[k]: sign clear = an opaque object was hit, bit 0 clear = a refractive one was)
       uint32_t both_any = 0u;
 #pragma unroll
       for (int k = 0; k < B; ++k) {
-        const uint32_t ms = __float_as_uint(m[k]), gs = __float_as_uint(mrf[k]);
-        m[k] = __uint_as_float(ms | ~gs);                        // sign set: lit (what the weights below look at)
-        mrf[k] = __uint_as_float(ms | gs);                       // sign clear: both kinds
-        both_any |= ~(ms | gs);
+        const uint32_t w = __float_as_uint(m[k]);
+        both_any |= ~(w | (w << 31));                            // sign set: both kinds
         asm volatile("" : "+v"(both_any));
       }
       if (__ballot(int(both_any) < 0) != 0ull) {
 #pragma unroll
         for (int k = 0; k < B; ++k) {
-          if (int(__float_as_uint(mrf[k])) >= 0 && base + k < nrays) {
+          const uint32_t wk = __float_as_uint(m[k]);
+          if (int(wk | (wk << 31)) >= 0 && base + k < nrays) {
             float t = INFINITY;
             int hi = -1, face;
             if (n <= 64 && nc <= 32) {
@@ -402,9 +405,14 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
               nearest_object<CUBES>(sg, gg, n, nc, sx, sy, sz, Lx[k], Ly[k], Lz[k], t, hi, face);
             }
             const bool blocked = hi >= 0 && !(refr[hi >= 0 ? hi : 0].x > 0.0f);
-            m[k] = blocked ? 0.0f : -1.0f;
+            m[k] = __uint_as_float(blocked ? 0x00000001u : 0x80000001u);    // as if only the nearest kind had been hit
           }
         }
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const uint32_t w = __float_as_uint(m[k]);
+        m[k] = __uint_as_float(w | ~(w << 31));                  // sign set: lit — no opaque hit, or some refractive one (what the weights look at)
       }
     }
 #pragma unroll
