@@ -146,6 +146,9 @@ constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shad
 #else
 #define RT_NOW() 0ull
 #endif
+#ifndef RT_LIGHT_ALL
+#define RT_LIGHT_ALL 1     // a copy of lighting() for lights that ask for exactly one batch of rays (no per-ray guard)
+#endif
 #ifndef RT_SHADOW_BATCH
 #define RT_SHADOW_BATCH 13
 #endif

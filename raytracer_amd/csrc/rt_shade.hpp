@@ -48,7 +48,9 @@ __device__ __forceinline__ void light_colour(const DevLights& L, const LightSums
   lb = fmaf(mb * L.pcol[2], pk, L.pcol[2] * psk) + L.acol[2] * (ak + ask);
 }
 
-template <int MODE, int B, bool REFR = false, bool CUBES = false, bool LIST = false>
+// (ALL: the caller has checked that the lights ask for exactly B rays — the reference's 1 + 12 — so one batch holds them all and
+// no ray needs the "beyond the light's sample count" guard: three scalar instructions and a select per ray)
+template <int MODE, int B, bool REFR = false, bool CUBES = false, bool LIST = false, bool ALL = false>
 __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* __restrict__ sg,
                                          const float4* __restrict__ gg, const float2* __restrict__ refr,
                                          const uint32_t* __restrict__ glass_bits,
@@ -58,7 +60,7 @@ __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* 
 #if RT_CULL_STATS
   unsigned dbg_rel_ = 0, dbg_lanes_ = 0, dbg_iters_ = 0, dbg_turns_ = 0;
 #endif
-  const int nrays = 1 + L.ns;
+  const int nrays = ALL ? B : 1 + L.ns;
   const float vdn = -(fmaf(dz, nz, fmaf(dy, ny, dx * nx)));  // view . normal, view = -D (:257)
   float pd = 0.f, ps = 0.f;  // point light: diffuse, specular (unshadowed)
   float ad = 0.f, as = 0.f;  // area light: sums over unshadowed samples
@@ -463,10 +465,16 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-  const LightSums w = lighting<MODE, (CUBES ? kCubeShadowBatch : kShadowBatch), false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr,
-                               LIST ? p.occl_start + occluder_row(p.occl_list_dim, idx, nx, ny, nz)
-                                    : p.occl + occluder_row(p.occl_dim, idx, nx, ny, nz) * size_t(p.occl_words), p.occl_items, p.n_spheres, p.n_cubes, px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz,
-                               level_key);
+  const uint32_t* row = LIST ? p.occl_start + occluder_row(p.occl_list_dim, idx, nx, ny, nz)
+                             : p.occl + occluder_row(p.occl_dim, idx, nx, ny, nz) * size_t(p.occl_words);
+  constexpr int kB = CUBES ? kCubeShadowBatch : kShadowBatch;
+  LightSums w;
+  if (RT_LIGHT_ALL && 1 + p.L.ns == kB)      // (wave-uniform) the reference's lights: all rays in one batch, none of them idle
+    w = lighting<MODE, kB, false, CUBES, LIST, true>(p.L, sg, p.geom, nullptr, nullptr, row, p.occl_items, p.n_spheres, p.n_cubes,
+                                                       px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, level_key);
+  else
+    w = lighting<MODE, kB, false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr, row, p.occl_items, p.n_spheres, p.n_cubes,
+                                                px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, level_key);
   float4 m;
   float spec;
   late.load(m, spec);
