@@ -183,6 +183,17 @@ int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(ctx, RT_EDEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+// Every sample of the area light, A + u (r_u - 0.5) + v (r_v - 0.5) with r in [0, 1) (raytracer.py:180-183), lies in the
+// parallelogram spanned by u and v about A: its farthest points are corners, at half a diagonal — max(|u + v|, |u - v|) / 2
+// (0.71 for the reference's unit square; 0.5 (|u| + |v|) = 1.0, the bound used until round 3, made every shadow cone 41 % wider).
+float area_light_radius(const float* u, const float* v) {
+  double p = 0.0, m = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    p += (double(u[k]) + v[k]) * (double(u[k]) + v[k]);
+    m += (double(u[k]) - v[k]) * (double(u[k]) - v[k]);
+  }
+  return float(0.5 * std::sqrt(std::max(p, m)) * (1.0 + 1e-6));
+}
 size_t geom_lds(int n_spheres) { return size_t((n_spheres * 16 + 15) / 16) * 16; }
 size_t stream_lds(int n_spheres, int refr = 0, int out = 0, int waves = kBlock / 64) {
   return geom_lds(n_spheres) + size_t(wave_lds_bytes(refr, out)) * size_t(waves);
@@ -570,7 +581,15 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
 // The occluder table of lighting()'s shadow scan for the context's spheres (ctx->h_geom, ctx->lights) and `n_boxes` boxes
 // behind them: bit-mask rows per (object, bucket of the surface normal) — boxes: every sphere, every bucket — and, from
 // kGridFrom spheres on, the same rows as lists for the list kernels.  Host build (FP64), one copy to the device.
+int upload_occluder_rows(rt_ctx* ctx, int n_boxes);
 int upload_occluder_table(rt_ctx* ctx, int n_boxes) {
+  // (a failure leaves rows of one layout under the dimensions of another: the context then holds no scene at all, and
+  // renders return RT_ESTATE until the next rt_upload_scene)
+  const int rc = upload_occluder_rows(ctx, n_boxes);
+  if (rc != RT_OK) ctx->n_spheres = -1;
+  return rc;
+}
+int upload_occluder_rows(rt_ctx* ctx, int n_boxes) {
   const int n = int(ctx->h_geom.size() / 4), words = (n + 31) / 32;
   ctx->occl_dim = 0; ctx->occl_list_dim = 0;
   if (n == 0) return RT_OK;
@@ -857,8 +876,7 @@ int rt_upload_scene(rt_ctx* ctx, const float* geom4, const float* mat4, const fl
   memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
   memcpy(L.acol, lights->area_color, 12);
   L.aint = lights->area_intensity; L.ns = lights->area_samples; L.inv_ns = 1.0f / float(L.ns);
-  L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
-                   std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
+  L.arad = area_light_radius(L.au, L.av);
   ctx->h_geom.assign(geom4, geom4 + size_t(4) * size_t(n_spheres));   // (rt_set_cubes builds the tables again, with the boxes)
   if (int rc = upload_occluder_table(ctx, 0)) return rc;
   ctx->list_dim = 0;
@@ -952,8 +970,7 @@ int rt_occluder_table(const float* geom4, int n_spheres, const rt_lights* lights
   DevLights L{};
   memcpy(L.ppos, lights->point_pos, 12);
   memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
-  L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
-                   std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
+  L.arad = area_light_radius(L.au, L.av);
   std::vector<uint32_t> tab;
   build_occluder_table(geom4, n_spheres, L, tab);
   const size_t words = size_t(n_spheres) * size_t((n_spheres + 31) / 32);
@@ -967,8 +984,7 @@ int rt_occluder_table_buckets(const float* geom4, int n_spheres, const rt_lights
   DevLights L{};
   memcpy(L.ppos, lights->point_pos, 12);
   memcpy(L.apos, lights->area_pos, 12); memcpy(L.au, lights->area_u, 12); memcpy(L.av, lights->area_v, 12);
-  L.arad = 0.5f * (std::sqrt(L.au[0] * L.au[0] + L.au[1] * L.au[1] + L.au[2] * L.au[2]) +
-                   std::sqrt(L.av[0] * L.av[0] + L.av[1] * L.av[1] + L.av[2] * L.av[2]));
+  L.arad = area_light_radius(L.au, L.av);
   std::vector<uint32_t> object_rows, tab;
   build_occluder_table(geom4, n_spheres, L, object_rows);
   build_occluder_buckets(geom4, n_spheres, L, dim, object_rows, tab);

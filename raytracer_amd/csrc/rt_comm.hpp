@@ -28,14 +28,15 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mutex;
-std::string g_rccl_error;
 
 // Binds librccl once per process.  Order: the copy already mapped into the process (RTLD_NOLOAD: torch's, when the host
 // is raytracer_amd — two RCCLs in one process would each bring their own kernels and IPC state), RT355_RCCL_LIB, the
 // loader's search path, ROCm's directory.
-const RcclApi* rccl_api() {
+// (`why`: the caller's own string — the reason when nullptr comes back)
+const RcclApi* rccl_api(std::string& why_not) {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.handle) return &g_rccl;
+  std::string& error = why_not;
   void* h = nullptr;
   for (const char* name : {"librccl.so.1", "librccl.so"})
     if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
@@ -47,7 +48,7 @@ const RcclApi* rccl_api() {
     if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
   if (!h) {
     const char* why = dlerror();
-    g_rccl_error = std::string("librccl.so.1 could not be loaded (") + (why ? why : "no reason given") +
+    error = std::string("librccl.so.1 could not be loaded (") + (why ? why : "no reason given") +
                    "); set RT355_RCCL_LIB to its path";
     return nullptr;
   }
@@ -55,10 +56,10 @@ const RcclApi* rccl_api() {
   api.handle = h;
   auto bind = [&](auto& fn, const char* name) {
     fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, name));
-    if (!fn && g_rccl_error.empty()) g_rccl_error = std::string("librccl has no symbol ") + name;
+    if (!fn && error.empty()) error = std::string("librccl has no symbol ") + name;
     return fn != nullptr;
   };
-  g_rccl_error.clear();
+  error.clear();
   bool ok = true;     // (every symbol is looked up: the message names the first one that is missing)
   ok = bind(api.GetVersion, "ncclGetVersion") && ok;
   ok = bind(api.GetUniqueId, "ncclGetUniqueId") && ok;
@@ -88,8 +89,9 @@ extern "C" {
 
 int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]) {
   if (!id) return fail(nullptr, RT_EINVAL, "rt_comm_unique_id: id is NULL");
-  const RcclApi* api = rccl_api();
-  if (!api) return fail(nullptr, RT_EDEVICE, "rt_comm_unique_id: %s", g_rccl_error.c_str());
+  std::string why;
+  const RcclApi* api = rccl_api(why);
+  if (!api) return fail(nullptr, RT_EDEVICE, "rt_comm_unique_id: %s", why.c_str());
   RcclUniqueId u;
   RT_RCCL(nullptr, api, api->GetUniqueId(&u));
   memcpy(id, u.internal, RT_COMM_ID_BYTES);
@@ -101,8 +103,9 @@ int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int n_ranks, i
   if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
     return fail(ctx, RT_EINVAL, "rt_comm_init: bad argument (id %p, n_ranks %d, rank %d)", (const void*)id, n_ranks, rank);
   if (ctx->comm) return fail(ctx, RT_ESTATE, "rt_comm_init: the context already holds a communicator (rt_comm_destroy first)");
-  const RcclApi* api = rccl_api();
-  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_init: %s", g_rccl_error.c_str());
+  std::string why;
+  const RcclApi* api = rccl_api(why);
+  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_init: %s", why.c_str());
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RcclUniqueId u;
   memcpy(u.internal, id, RT_COMM_ID_BYTES);
@@ -115,10 +118,11 @@ int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], int n_ranks, i
 int rt_comm_destroy(rt_ctx* ctx) {
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (!ctx->comm) return RT_OK;
-  const RcclApi* api = rccl_api();
+  std::string why;
+  const RcclApi* api = rccl_api(why);
   void* comm = ctx->comm;
   ctx->comm = nullptr; ctx->comm_ranks = 0; ctx->comm_rank = -1;
-  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_destroy: %s", g_rccl_error.c_str());
+  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_destroy: %s", why.c_str());
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_RCCL(ctx, api, api->CommDestroy(comm));
   return RT_OK;
@@ -139,8 +143,9 @@ int rt_comm_all_gather_counts(rt_ctx* ctx, const uint32_t* count_dev, uint32_t* 
   if (!ctx) return fail(nullptr, RT_EINVAL, "ctx is NULL");
   if (!ctx->comm) return fail(ctx, RT_ESTATE, "rt_comm_all_gather_counts: no communicator (rt_comm_init first)");
   if (!count_dev || !counts_all_dev) return fail(ctx, RT_EINVAL, "rt_comm_all_gather_counts: NULL buffer");
-  const RcclApi* api = rccl_api();
-  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_all_gather_counts: %s", g_rccl_error.c_str());
+  std::string why;
+  const RcclApi* api = rccl_api(why);
+  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_all_gather_counts: %s", why.c_str());
   RT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
   RT_RCCL(ctx, api, api->AllGather(count_dev, counts_all_dev, 1, kRcclUint32, ctx->comm, s));
@@ -167,8 +172,9 @@ int rt_comm_gather(rt_ctx* ctx, const void* send, int64_t send_bytes, void* gath
       return fail(ctx, RT_EINVAL, "rt_comm_gather: the root sends %lld bytes but expects %lld from itself",
                   (long long)send_bytes, (long long)recv_bytes[me]);
   }
-  const RcclApi* api = rccl_api();
-  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_gather: %s", g_rccl_error.c_str());
+  std::string why;
+  const RcclApi* api = rccl_api(why);
+  if (!api) return fail(ctx, RT_EDEVICE, "rt_comm_gather: %s", why.c_str());
   RT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
   RT_RCCL(ctx, api, api->GroupStart());

@@ -10,7 +10,7 @@ struct DevLights {
   float ppos[3], pcol[3], pint;
   float apos[3], au[3], av[3], acol[3], aint;
   int ns;
-  float arad;   // 0.5 (|au| + |av|): every area-light sample lies within this distance of apos
+  float arad;   // max(|au + av|, |au - av|) / 2: every area-light sample lies within this distance of apos
   float inv_ns; // RN(1 / ns): what `1.0f / float(ns)` gives, formed once on the host instead of per shaded hit (10 instructions)
 };
 
