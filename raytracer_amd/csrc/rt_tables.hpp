@@ -120,6 +120,7 @@ void build_reflect_table(const float* geom4, int n, int B, std::vector<uint2>& t
 // build runs on several threads.  Returns false — no table, reflection rays scan every sphere — if the lists would exceed
 // kReflListMaxChunks (a scene where most spheres reach most directions of most objects: huge or interlocked spheres).
 constexpr int kReflListDim = RT_REFL_LIST_DIM;
+constexpr int kReflListFineTo = 1280;     // scenes of up to this many spheres: twice as many buckets per face edge
 constexpr size_t kReflListMaxChunks = size_t(32) << 20;   // 256 MB of indices
 bool build_reflect_lists(const float* geom4, int n, int B, std::vector<uint32_t>& start, std::vector<uint2>& items) {
   const int nb = 6 * B * B;
