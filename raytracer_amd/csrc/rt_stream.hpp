@@ -245,6 +245,8 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
 
   const int gwave = __builtin_amdgcn_readfirstlane(int(blockIdx.x) * (kThreads / 64) + wave);
   const int n_waves = int(gridDim.x) * (kThreads / 64);
+  // ray statistics, wave-uniform (scalar registers: as per-lane counters they held two vector registers through every phase
+  // of the kernel, and the many-sphere variants spilled them to scratch and back once per pass)
   uint32_t n_trace = 0, n_shade = 0;
   [[maybe_unused]] unsigned long long st_fetch = 0, st_pop = 0, st_light = 0, st_near = 0;     // (read in RT_STAMPS builds only)
   [[maybe_unused]] const unsigned long long st_begin = RT_NOW();
@@ -685,8 +687,9 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
         float rpx = 0.f, rpy = 0.f, rpz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rtr = 0.f, rtg = 0.f, rtb = 0.f;
         float fpx = 0.f, fpy = 0.f, fpz = 0.f, fdx = 0.f, fdy = 0.f, fdz = 0.f, ftr = 0.f, ftg = 0.f, ftb = 0.f;
         uint32_t meta_r = 0u, meta_f = 0u;
+        bool traced_r = false, traced_f = false;
+        n_shade += uint32_t(nb);
         if (have) {
-          ++n_shade;
           float nx, ny, nz, sx, sy, sz, lr, lg, lb;
           float4 m;
           float2 rf;
@@ -740,7 +743,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             rdx = fmaf(-dn2, nx, dx); rdy = fmaf(-dn2, ny, dy); rdz = fmaf(-dn2, nz, dz);
             float t;
             int idx2, face;
-            ++n_trace;
+            traced_r = true;
             if (p.refl_dim > 0) nearest_table<CUBES>(p, sg, meta_object(meta), sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
             else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, sx, sy, sz, rdx, rdy, rdz, t, idx2, face);
             if (idx2 >= 0) {
@@ -769,7 +772,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
               const float ox = fmaf(qx, -0.001f, px), oy = fmaf(qy, -0.001f, py), oz = fmaf(qz, -0.001f, pz);  // :229
               float t;
               int idx2, face;
-              ++n_trace;
+              traced_f = true;
               // (the refracted ray starts 0.001 INSIDE the object: still within reach of the table's bound)
               if (p.refl_dim > 0) nearest_table<CUBES>(p, sg, meta_object(meta), ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
               else nearest_object<CUBES>(sg, p.geom, p.n_spheres, p.n_cubes, ox, oy, oz, fdx, fdy, fdz, t, idx2, face);
@@ -783,6 +786,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
           }
         }
         wave_lds_fence();   // every lane has its whole record in registers before slots are rewritten
+        n_trace += uint32_t(__popcll(__ballot(traced_r)) + __popcll(__ballot(traced_f)));
         const unsigned long long mask_r = __ballot(push_r), mask_f = __ballot(push_f);
         // (slot < kCap always holds by the pass sizing above; the test only keeps a logic error from
         // becoming a stray LDS write)
@@ -829,8 +833,9 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
 #endif
         continue;
       }
+      n_shade += uint32_t(nb);
+      bool traced = false;
       if (have) {
-        ++n_shade;
         float ox, oy, oz;
         bool cont;
         {
@@ -844,10 +849,10 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
         const int level = meta_level(meta);                          // (the meta word as re-read behind lighting())
         cont = cont && (level < p.max_depth);                        // :233 `depth > D` -> black
         s2 = RT_NOW();
+        traced = cont;
         if (cont) {
           float t;
           int idx2, face;
-          ++n_trace;
           if constexpr (GRID != 0) {
             if (p.list_dim > 0) nearest_list(p, sg, meta_object(meta), ox, oy, oz, dx, dy, dz, t, idx2);
             else nearest_hit(sg, p.geom, p.n_spheres, ox, oy, oz, dx, dy, dz, t, idx2);   // (RT_OPT_REFLECT_TABLE off, or lists beyond 256 MB)
@@ -880,6 +885,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
         }
       }
       wave_lds_fence();   // every lane has its whole record in registers before slots are rewritten
+      n_trace += uint32_t(__popcll(__ballot(traced)));
       const unsigned long long mask = __ballot(again);
       if (again) {
         const int slot = base + lanes_below(mask);
@@ -922,12 +928,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
   const RenderParams& p = params_here();
   const int lane = lane_here();
   if (p.counters) {
-    unsigned long long tot_t = n_trace, tot_s = n_shade;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      tot_t += __shfl_xor(tot_t, o);
-      tot_s += __shfl_xor(tot_s, o);
-    }
+    const unsigned long long tot_t = n_trace, tot_s = n_shade;      // (a wave shades fewer than 2^32 records per launch)
     if (lane == 0) {
       unsigned long long* slot = p.counters + size_t(gwave % kCounterSlots) * kCounterWords;
       if (tot_t) atomicAdd(slot + 0, tot_t);
