@@ -155,7 +155,7 @@ constexpr int kCounterWords = 16;  // per slot: 0 trace 1 shade 2 primary 3 shad
 constexpr int kShadowBatch = RT_SHADOW_BATCH;   // shadow rays traced together: 1 point-light ray + 12 area-light rays (raytracer.py:80) by default
 constexpr int kReferenceShadowRays = 13;
 #ifndef RT_REFR_BATCH
-#define RT_REFR_BATCH 7
+#define RT_REFR_BATCH 13     // (7 while the kernels were short of registers; see kRefrShadowBatch)
 #endif
 #ifndef RT_REFR_WAVES
 #define RT_REFR_WAVES 4     // waves per SIMD the REFR slot variants are compiled for (their LDS holds three workgroups per CU)
@@ -172,7 +172,7 @@ constexpr int kReferenceShadowRays = 13;
 #endif
 constexpr int kCubeShadowBatch = RT_CUBE_BATCH;            // scenes with boxes
 constexpr int kRefrCubeShadowBatch = RT_REFR_CUBE_BATCH;   // ... and refractive materials
-constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: the tree's two children are formed behind lighting(), so fewer rays per batch fit the registers (7: 456 Grays/s on refractive_scene(), 9: 420, 10: 401, 13: 437)
+constexpr int kRefrShadowBatch = RT_REFR_BATCH;   // refractive scenes: all 13 rays in one batch since the per-lane ray counters left the vector registers (473 Grays/s on refractive_scene(); 7 + 6: 456, 10 + 3: 401; scenes with boxes stay at 7: 9 -> -10 %, 10 -> -15 %)
 
 // pixel kernel (one thread per pixel): 32 x 8 pixel tile per workgroup
 constexpr int kTileW = 32, kTileH = 8;
