@@ -123,7 +123,11 @@ struct RenderParams {
 #define RT_VIS_TILES 4     // 8x8 tiles (pixels per lane) of one visibility-pass wave: 2 -> +5 %, 4 -> +8 % on config 2 (87 VGPRs)
 #endif
 #ifndef RT_VIS_WAVES
-#define RT_VIS_WAVES 5     // its __launch_bounds__ occupancy target (waves per SIMD); 8 with 3+ tiles spills
+#define RT_VIS_WAVES 4     // its __launch_bounds__ occupancy target (waves per SIMD): 108 VGPRs and no spill; at 5 (96 VGPRs, 60 bytes of scratch
+                           // since the region culls its blocks jointly) config 2 / target / config 3 / config 1 ran 0.9 / 1.2 / 1.7 / 1.9 % slower
+#endif
+#ifndef RT_VIS_WAVES_MANY
+#define RT_VIS_WAVES_MANY 5   // the many-sphere variant (config 4: 4 -> -2.9 %)
 #endif
 constexpr int kVisTiles = RT_VIS_TILES;
 #ifndef RT_VIS_REGION_BLOCKS

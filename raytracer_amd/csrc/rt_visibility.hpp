@@ -321,7 +321,7 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
 #endif
 constexpr int kVisRows = RT_VIS_ROWS;
 template <int MODE, bool CUBES, bool MULTI = false, bool MANY = false>
-__global__ __launch_bounds__(RT_VIS_BLOCK, RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
+__global__ __launch_bounds__(RT_VIS_BLOCK, MANY ? RT_VIS_WAVES_MANY : RT_VIS_WAVES) void rt_visibility_kernel(const RenderParams p) {
   static_assert(!MANY || !CUBES, "the many-sphere form of the pass exists for scenes without cubes");
   constexpr int NT = kVisTiles;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
