@@ -702,7 +702,7 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             const uint32_t* row = p.occl + occluder_row(p.occl_dim, idx, nx, ny, nz) * size_t(p.occl_words);
             const uint32_t lkey = mix(pixel_key, uint32_t(meta_level(meta) + 1));
             LightSums lw;
-            if (RT_LIGHT_ALL && 1 + p.L.ns == kB)      // (wave-uniform) the reference's lights: one batch holds every ray
+            if (RT_LIGHT_ALL && 2 * kB >= kReferenceShadowRays && 1 + p.L.ns == kReferenceShadowRays)      // (wave-uniform) the reference's lights: one batch holds every ray
               lw = lighting<MODE, kB, true, CUBES, false, true>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), row, nullptr, p.n_spheres, p.n_cubes,
                                                                 px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, lkey);
             else
