@@ -1,6 +1,7 @@
 """GPU box: random scenes with cubes (opaque and refractive, boxes around lights, around the camera, behind surfaces),
-one digest per case of frame + hit map.  Run once with the shipped library and once with a -DRT_CUBE_SHADOW_CULL=0
-build (RT355_LIB=...), and compare the two outputs: the candidate-box cull of lighting() must not change a byte.
+one digest per case of frame + hit map, rendered three times: default, direction table off, occluder table off (must agree).
+Run once with the shipped library and once with a -DRT_CUBE_SHADOW_CULL=0 build (RT355_LIB=...), and compare the two outputs:
+the candidate-box cull of lighting() must not change a byte either.
     python tools/fuzz_cubes.py [cases] [seed] > a.txt;  RT355_LIB=$PWD/nocull.so python tools/fuzz_cubes.py [cases] [seed] > b.txt;  cmp a.txt b.txt"""
 import hashlib, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -51,11 +52,14 @@ for case in range(n_cases):
     cam = None if rng.integers(0, 3) == 0 else orbit_camera(int(rng.integers(0, 256)), 256, radius=float(rng.uniform(3, 12)))
     w, h_, D = int(rng.integers(100, 500)), int(rng.integers(60, 300)), int(rng.integers(0, 6))
     dig = []
-    for kernel in ("stream",):      # (the one-thread-per-pixel kernel takes no cubes)
-        r.set_kernel(kernel); r.upload_scene(sc)
+    # (the one-thread-per-pixel kernel takes no cubes.)  In-process: the default path, then without the direction table of
+    # secondary rays (boxes as sources and targets), then without the occluder table — the same bytes (glass: integer sums)
+    for refl, occl in ((True, True), (False, True), (True, False)):
+        r.set_reflect_table(refl); r.set_occluder_table(occl); r.upload_scene(sc)
         img, hit = r.render(w, h_, 1, max_depth=D, rng_mode="K", seed=case, camera=cam, return_hit_index=True)
         hsh = hashlib.sha256(img.cpu().numpy().tobytes() + hit.cpu().numpy().tobytes()).hexdigest()[:16]
         dig.append(hsh)
         lit = float((img.max(-1).values > 0).float().mean())
-    r.set_kernel("stream")
-    print(f"case {case}: spheres={n} objects={len(objs)} glass={bool(glass)} {w}x{h_} D={D} ext={ext} lit={lit:.3f} digest={dig[0]}", flush=True)
+    r.set_reflect_table(True); r.set_occluder_table(True)
+    same = "same" if len(set(dig)) == 1 else "DIFFERENT " + " ".join(dig)
+    print(f"case {case}: spheres={n} objects={len(objs)} glass={bool(glass)} {w}x{h_} D={D} ext={ext} lit={lit:.3f} digest={dig[0]} tables on/off: {same}", flush=True)
