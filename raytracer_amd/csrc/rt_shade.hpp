@@ -55,7 +55,7 @@ template <int MODE, int B, bool REFR = false, bool CUBES = false, bool LIST = fa
 __device__ __forceinline__ LightSums lighting(const DevLights& L, const float4* __restrict__ sg,
                                          const float4* __restrict__ gg, const float2* __restrict__ refr,
                                          const uint32_t* __restrict__ glass_bits,
-                                         const uint32_t* __restrict__ occl_row, const uint2* __restrict__ occl_items, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
+                                         const uint32_t* __restrict__ occl_base, uint32_t occl_off, const uint2* __restrict__ occl_items, int n, int nc, float px, float py, float pz, float nx, float ny, float nz,
                                          float dx, float dy, float dz, float sx, float sy, float sz,
                                          uint32_t level_key) {
 #if RT_CULL_STATS
@@ -128,15 +128,18 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& p, const float4* _
   surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
   // shadow-ray origin (:184, :199) — also the reflection origin (:247)
   const float sx = fmaf(nx, 0.001f, px), sy = fmaf(ny, 0.001f, py), sz = fmaf(nz, 0.001f, pz);
-  const uint32_t* row = LIST ? p.occl_start + occluder_row(p.occl_list_dim, idx, nx, ny, nz)
-                             : p.occl + occluder_row(p.occl_dim, idx, nx, ny, nz) * size_t(p.occl_words);
+  // (the row of the occluder table as a wave-uniform base and a 32-bit offset of the lane's own: the 64-bit address, formed here,
+  // was two registers live through the ray set-up)
+  // (the list kernels keep the address: with the offset form they spill 7 registers instead of 3, config 4 -4 %)
+  const uint32_t* occl_base = LIST ? p.occl_start + occluder_row(p.occl_list_dim, idx, nx, ny, nz) : p.occl;
+  const uint32_t occl_off = LIST ? 0u : uint32_t(occluder_row(p.occl_dim, idx, nx, ny, nz)) * uint32_t(p.occl_words);
   constexpr int kB = CUBES ? kCubeShadowBatch : kShadowBatch;
   LightSums w;
   if (RT_LIGHT_ALL && 2 * kB >= kReferenceShadowRays && 1 + p.L.ns == kReferenceShadowRays)      // (wave-uniform) the reference's lights: all rays in one batch, none of them idle
-    w = lighting<MODE, kB, false, CUBES, LIST, true>(p.L, sg, p.geom, nullptr, nullptr, row, p.occl_items, p.n_spheres, p.n_cubes,
+    w = lighting<MODE, kB, false, CUBES, LIST, true>(p.L, sg, p.geom, nullptr, nullptr, occl_base, occl_off, p.occl_items, p.n_spheres, p.n_cubes,
                                                        px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, level_key);
   else
-    w = lighting<MODE, kB, false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr, row, p.occl_items, p.n_spheres, p.n_cubes,
+    w = lighting<MODE, kB, false, CUBES, LIST>(p.L, sg, p.geom, nullptr, nullptr, occl_base, occl_off, p.occl_items, p.n_spheres, p.n_cubes,
                                                 px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, level_key);
   float4 m;
   float spec;

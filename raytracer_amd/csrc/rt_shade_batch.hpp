@@ -127,8 +127,8 @@
         // Many spheres: the object's candidates come as a list (chunks of four indices, the next chunk requested
         // before this one is looked at) instead of 32 .. 64 mostly empty mask words, each a load of its own.
         // Up to 32 candidates are culled at a time; the survivors' positions go into `rel` and are tested below.
-        uint32_t c = occl_row[0];
-        const uint32_t e = occl_row[1];
+        uint32_t c = occl_base[occl_off];
+        const uint32_t e = occl_base[occl_off + 1u];
         while (__ballot(c < e) != 0ull) {
           const uint32_t c0 = c;
           uint32_t rel = 0u;
@@ -163,7 +163,7 @@
         // candidates: the spheres that can shadow SOME point of the object this lane shades (a table
         // built at scene upload: every ray from the object towards a light lies in one cone, and few
         // spheres reach into it).  Lanes shade different objects, so each walks its own bit list.
-        uint32_t cand = occl_row[word];
+        uint32_t cand = occl_base[occl_off + uint32_t(word)];
         uint32_t rel = 0u;
         if (SHARE && base > 0 && n <= 64) { cand = 0u; rel = word == 0 ? kept0 : kept1; }   // (the first batch's survivors)
         while (__ballot(cand != 0u) != 0ull) {

@@ -699,14 +699,14 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             surface_normal<CUBES>(sg, p.n_spheres, idx, px, py, pz, nx, ny, nz);   // :139-140 / :142-150
             sx = fmaf(nx, 0.001f, px); sy = fmaf(ny, 0.001f, py); sz = fmaf(nz, 0.001f, pz);
             constexpr int kB = CUBES ? kRefrCubeShadowBatch : kRefrShadowBatch;
-            const uint32_t* row = p.occl + occluder_row(p.occl_dim, idx, nx, ny, nz) * size_t(p.occl_words);
+            const uint32_t row = uint32_t(occluder_row(p.occl_dim, idx, nx, ny, nz)) * uint32_t(p.occl_words);
             const uint32_t lkey = mix(pixel_key, uint32_t(meta_level(meta) + 1));
             LightSums lw;
             if (RT_LIGHT_ALL && 2 * kB >= kReferenceShadowRays && 1 + p.L.ns == kReferenceShadowRays)      // (wave-uniform) the reference's lights: one batch holds every ray
-              lw = lighting<MODE, kB, true, CUBES, false, true>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), row, nullptr, p.n_spheres, p.n_cubes,
+              lw = lighting<MODE, kB, true, CUBES, false, true>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl, row, nullptr, p.n_spheres, p.n_cubes,
                                                                 px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, lkey);
             else
-              lw = lighting<MODE, kB, true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), row, nullptr, p.n_spheres, p.n_cubes,
+              lw = lighting<MODE, kB, true, CUBES>(p.L, sg, p.geom, p.refr, as_const(p.glass_bits), p.occl, row, nullptr, p.n_spheres, p.n_cubes,
                                                    px, py, pz, nx, ny, nz, dx, dy, dz, sx, sy, sz, lkey);
             // (material, record state and the meta word come in BEHIND the shadow loops, as in the opaque path:
             // the 13-ray batch leaves no registers for them)
