@@ -146,12 +146,14 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
     // a block that no sphere reaches builds no rays: all its pixels miss (with more than 64 spheres the later
     // chunks are not looked at here, and with cubes every ray is needed for them)
     bool cube_reach = false;
+    [[maybe_unused]] unsigned long long cube_mask = ~0ull;   // boxes 0..63 whose double cone the block's rays can meet (all, where not asked)
     if constexpr (CUBES) {   // (one cube per lane; beyond 64 cubes, or without a cone — no spheres at all —, every ray is built)
       cube_reach = true;
       if (cull && p.n_cubes <= 64) {
         const int c = lane < p.n_cubes ? lane : p.n_cubes - 1;
-        cube_reach = __ballot(lane < p.n_cubes && box_in_double_cone(p.cubes[2 * c], p.cubes[2 * c + 1], cone, cam.origin[0],
-                                                                     cam.origin[1], cam.origin[2])) != 0ull;
+        cube_mask = __ballot(lane < p.n_cubes && box_in_double_cone(p.cubes[2 * c], p.cubes[2 * c + 1], cone, cam.origin[0],
+                                                                    cam.origin[1], cam.origin[2]));
+        cube_reach = cube_mask != 0ull;
       }
     }
     const bool need_rays = !RT_VIS_SKIP || cube_reach || reached != 0ull || (p.n_spheres > 64 && !region_kept);
@@ -191,7 +193,10 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
       float ix[NT], iy[NT], iz[NT];
 #pragma unroll
       for (int q = 0; q < NT; ++q) { ix[q] = frcp(dx[q]); iy[q] = frcp(dy[q]); iz[q] = frcp(dz[q]); }
+      // (only the boxes the block's cone — or its mirror image — can meet, in index order: a box it cannot meet is hit by no ray of
+      // the block, so the nearest hit and the lowest index on a tie are those of the full scan)
       for (int c = 0; c < p.n_cubes; ++c) {
+        if (c < 64 && ((cube_mask >> c) & 1ull) == 0ull) continue;
         const float4 lo = cg[2 * c], hi = cg[2 * c + 1];
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
