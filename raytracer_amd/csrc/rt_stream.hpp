@@ -713,6 +713,9 @@ __global__ __launch_bounds__((GRID == 3 ? 1024 : (GRID == 2 || OUT == 4) ? 512 :
             float spec;
             LateFromRecord late{p, late_state, q, e, meta, base, lane_here()};
             late.load(m, spec);
+            // (the hit point again, from the record: the refracted ray starts from it below, and held in registers through the
+            // shadow loops two of its three words went to scratch)
+            px = q.at(0, e); py = q.at(1, e); pz = q.at(2, e);
             rf = p.refr[meta_object(meta)];
             light_colour(p.L, lw, m.x, m.y, m.z, spec, lr, lg, lb);
           }
