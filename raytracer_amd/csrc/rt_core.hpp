@@ -703,7 +703,7 @@ __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg
                                                    bool kept, uint32_t keep_lo, uint32_t keep_hi,
                                                    float ox, float oy, float oz, const float (&dx)[NP],
                                                    const float (&dy)[NP], const float (&dz)[NP], float (&best_t)[NP],
-                                                   int (&best_i)[NP]) {
+                                                   int (&best_i)[NP], uint32_t kept_chunks = 0u) {
   float inv_a[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
@@ -713,7 +713,9 @@ __device__ __forceinline__ void primary_hit_culled(const float4* __restrict__ gg
   }
   camtab_t tab = as_const(camtab);
   cgeom_t geom = as_const(gg);
-  for (int base = 0; base < n; base += 64) {
+  // (`kept`: only the chunks that hold a kept sphere — bit c of kept_chunks —, in increasing order as the plain walk)
+  for (int base = kept ? (kept_chunks ? (__ffs(int(kept_chunks)) - 1) * 64 : n) : 0; base < n;
+       base = kept ? ((kept_chunks &= kept_chunks - 1u) ? (__ffs(int(kept_chunks)) - 1) * 64 : n) : base + 64) {
     unsigned long long m = first;
     if (kept) {
       m = mask_of_chunk(keep_lo, keep_hi, base >> 6);

@@ -74,7 +74,8 @@ __device__ __forceinline__ RayCone bundle_cone_own(const RenderParams& p, const 
 template <int MODE, bool CUBES, bool MULTI, bool MANY = false>
 __device__ __forceinline__ void visibility_block(const RenderParams& p, const int frame, const int row0, const int col0,
                                                  const int lane, const uint32_t region_lo = 0u, const uint32_t region_hi = 0u,
-                                                 const bool pre = false, const unsigned long long pre_first = 0ull) {
+                                                 const bool pre = false, const unsigned long long pre_first = 0ull,
+                                                 const uint32_t region_chunks = 0u) {
   constexpr bool region_kept = MANY;      // (scenes of more than 64 spheres without cubes)
   // lane (lx, ly) traces pixel (lx, ly) of each tile
   constexpr int NT = kVisTiles;
@@ -129,9 +130,11 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
       const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
       cone = bundle_cone(p, cam, lane, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, yb);
       if (region_kept) {
-        for (int c = 0; c * 64 < p.n_spheres; ++c) {
+        // (only the chunks in which the region kept a sphere — bit c of region_chunks —: walking all 16 .. 32 chunks to find
+        // the two or three that hold something was most of the block's scalar work)
+        for (uint32_t rc = region_chunks; rc != 0u; rc &= rc - 1u) {
+          const int c = __ffs(int(rc)) - 1;
           const unsigned long long rm = mask_of_chunk(region_lo, region_hi, c);
-          if (rm == 0ull) continue;
           bool in = false;
           if ((rm >> lane) & 1ull) in = sphere_in_cone(p.geom[c * 64 + lane], cone, cam.origin[0], cam.origin[1], cam.origin[2]);
           const unsigned long long m = __ballot(in);
@@ -185,7 +188,8 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
     }
     if (p.n_spheres > kVisCullFrom)
       primary_hit_culled<NT>(p.geom, table, p.n_spheres, lane, cone, first, region_kept, keep_lo, keep_hi, cam.origin[0],
-                             cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
+                             cam.origin[1], cam.origin[2], dx, dy, dz, t, idx,
+                             region_kept ? uint32_t(__ballot((keep_lo | keep_hi) != 0u)) : 0u);
     else   // few spheres: every group is scanned (pipelined scalar loads: cheaper here than group-by-group fetches)
       primary_hit_n<NT>(p.geom, table, p.n_spheres, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, t, idx);
     if constexpr (CUBES) {   // the cubes of the object list (:159-160), wave-uniform scalar loads
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(RT_VIS_BLOCK, MANY ? RT_VIS_WAVES_MANY : RT_VIS_WAV
     // and everything derived from them would not fit the scalar registers)
     int lane_b = int(threadIdx.x) & 63;
     asm volatile("" : "+v"(lane_b));
-    visibility_block<MODE, CUBES, MULTI, MANY>(params_here(), frame, row0, col0, lane_b, region_lo, region_hi);
+    visibility_block<MODE, CUBES, MULTI, MANY>(params_here(), frame, row0, col0, lane_b, region_lo, region_hi, false, 0ull,
+                                               MANY ? uint32_t(__ballot((region_lo | region_hi) != 0u)) : 0u);
   }
 }
