@@ -75,7 +75,7 @@ template <int MODE, bool CUBES, bool MULTI, bool MANY = false>
 __device__ __forceinline__ void visibility_block(const RenderParams& p, const int frame, const int row0, const int col0,
                                                  const int lane, const uint32_t region_lo = 0u, const uint32_t region_hi = 0u,
                                                  const bool pre = false, const unsigned long long pre_first = 0ull,
-                                                 const uint32_t region_chunks = 0u) {
+                                                 const uint32_t region_chunks = 0u, const uint32_t pre_klo = 0u, const uint32_t pre_khi = 0u) {
   constexpr bool region_kept = MANY;      // (scenes of more than 64 spheres without cubes)
   // lane (lx, ly) traces pixel (lx, ly) of each tile
   constexpr int NT = kVisTiles;
@@ -123,8 +123,9 @@ __device__ __forceinline__ void visibility_block(const RenderParams& p, const in
     uint32_t keep_lo = 0u, keep_hi = 0u;
     unsigned long long reached = 0ull;
     if (cull && pre) {
-      first = pre_first;
-      reached = first;
+      first = pre_first;           // (many spheres: not a ballot of sphere indices, only "something reaches the block" — the kept
+      reached = first;             //  spheres come chunk by chunk in pre_klo / pre_khi, as the block's own cull would leave them)
+      keep_lo = pre_klo; keep_hi = pre_khi;
     } else if (cull) {
       const int ya = tile_rows_uniform(p) ? tile_row_base(p, row0) : row_of(p, row0);
       const int yb = (tile_rows_uniform(p) ? tile_row_base(p, row0) + 7 : row_of(p, min(row0 + 7, p.n_rows - 1))) + 1;
@@ -424,6 +425,54 @@ __global__ __launch_bounds__(RT_VIS_BLOCK, MANY ? RT_VIS_WAVES_MANY : RT_VIS_WAV
     // against the cone of that block's rays, and one ballot holds the verdicts of every block.  A block then starts from
     // its bits (visibility_block: `pre`) instead of building its cone and culling again with a handful of lanes at work:
     // 78 % of the blocks of config 2's kept regions are empty, and each spent ~150 instructions to find that out.
+    // The same for many spheres, where the region's kept spheres lie in the per-chunk ballots (lane c of region_lo / _hi): they
+    // are counted, and if k x blocks fit the wave, lane (block, j) fetches the j-th of them and tests it against the block's cone.
+    // A block's verdicts go back into the per-chunk form its scan reads (primary_hit_culled: `kept`).
+    if constexpr (MANY && RT_VIS_REGION_BLOCKS) {
+      const uint32_t rchunks = uint32_t(__ballot((region_lo | region_hi) != 0u));
+      int k = 0;
+      for (uint32_t rc = rchunks; rc != 0u; rc &= rc - 1u) k += __popcll(mask_of_chunk(region_lo, region_hi, __ffs(int(rc)) - 1));
+      if (k > 0 && k * kVisRows <= 64 && tile_rows_uniform(p)) {
+        const int magic = 65535 / k + 1;                      // lane / k for lane < 64 (exact: k <= 10)
+        const int b = (lane * magic) >> 16, j = lane - b * k;
+        int sphere = 0;
+        uint32_t where = 0u;                                  // lane i < k: (chunk << 6 | bit) of the i-th kept sphere
+        {
+          int i = 0;
+          for (uint32_t rc = rchunks; rc != 0u; rc &= rc - 1u) {
+            const int c = __ffs(int(rc)) - 1;
+            for (unsigned long long m = mask_of_chunk(region_lo, region_hi, c); m != 0ull; m &= m - 1ull, ++i) {
+              const int bit = __ffsll((long long)m) - 1;
+              if (j == i) sphere = c * 64 + bit;
+              if (lane == i) where = uint32_t(c << 6 | bit);
+            }
+          }
+        }
+        const float4 mine = p.geom[sphere];
+        const FrameRec fr = as_const(p.frames)[frame];
+        const int ya = tile_row_base_lane(p, rowR + 8 * b);
+        const RayCone cone = bundle_cone_own(p, fr.cam, p.x0 + col0, p.x0 + col0 + 8 * NT, ya, ya + 8);
+        const unsigned long long block_bits =
+            __ballot(lane < k * kVisRows && sphere_in_cone(mine, cone, fr.cam.origin[0], fr.cam.origin[1], fr.cam.origin[2]));
+#pragma nounroll
+        for (int bb = 0; bb < kVisRows; ++bb) {
+          const int row0 = rowR + 8 * bb;
+          if (row0 >= p.n_rows) break;
+          const uint32_t sub = uint32_t(block_bits >> (bb * k)) & ((1u << k) - 1u);     // (k <= 10)
+          int lane_b = int(threadIdx.x) & 63;
+          asm volatile("" : "+v"(lane_b));
+          uint32_t klo = 0u, khi = 0u;
+          for (uint32_t sb = sub; sb != 0u; sb &= sb - 1u) {
+            const uint32_t w = uint32_t(__builtin_amdgcn_readlane(int(where), __ffs(int(sb)) - 1));
+            const int c = int(w >> 6), bit = int(w & 63u);
+            if (lane_b == c) { if (bit < 32) klo |= 1u << bit; else khi |= 1u << (bit - 32); }
+          }
+          visibility_block<MODE, CUBES, MULTI, MANY>(params_here(), frame, row0, col0, lane_b, region_lo, region_hi, true,
+                                                     sub ? 1ull : 0ull, 0u, klo, khi);
+        }
+        return;
+      }
+    }
     if constexpr (!CUBES && !MANY && RT_VIS_REGION_BLOCKS) {
       const int k = __popcll(rmask);
       if (have_rmask && k * kVisRows <= 64 && tile_rows_uniform(p)) {
