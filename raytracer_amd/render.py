@@ -311,12 +311,19 @@ class Renderer:
         torch.distributed hands its 128 bytes round (plumbing: any channel would do), every rank joins
         (rt_comm_init).  After this the exchange of BatchExchange(comm=renderer) runs inside librt355."""
         import torch.distributed as dist
+        torch = _torch()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [None]
-        if rank == 0:
-            buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
-            self._check(self._L.rt_comm_unique_id(buf))
-            box[0] = bytes(buf)
+        # Every rank first makes an id of its own: that binds librccl and fails where it cannot be bound, BEFORE anything
+        # collective is entered — ncclCommInitRank would leave the ranks that did reach it waiting for the one that did not.
+        buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+        rc = self._L.rt_comm_unique_id(buf)
+        err = "" if rc == 0 else (self._L.rt_last_error(None) or b"unknown error").decode()
+        dev = f"cuda:{self.device}" if dist.get_backend(group) == "nccl" else "cpu"
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            raise RuntimeError("rt_comm_* is not available on every rank" + (f" (this rank: {err})" if err else ""))
+        box = [bytes(buf) if rank == 0 else None]          # rank 0's id is the communicator's
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
         self._check(self._L.rt_comm_init(self._h, ident, world, rank))
