@@ -1153,17 +1153,23 @@ int rt_compact_tiles(rt_ctx* ctx, const uint8_t* slab, uint8_t* entries, uint32_
     return fail(ctx, RT_ESTATE, "rt_compact_tiles: `slab` is not the frame buffer the last render call on this context wrote");
   const TileGeom& g = ctx->last.g;
   const long long total = (long long)g.tile_pitch * g.tiles8_y * g.n_frames;
+  if (total >= (1ll << 31)) return fail(ctx, RT_EINVAL, "rt_compact_tiles: %lld tile ids in the batch (at most 2^31 - 1)", total);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(uint32_t), ctx->stream));
   if (total == 0) return RT_OK;
-  const dim3 grid(unsigned((total + 255) / 256));
+  // a wave takes n_chunks x 64 consecutive slots of one of the kTileCounters counters (rt_compact_tiles_kernel): as many as
+  // leave about one wave per wave slot of the GPU — fewer atomics on the one count, yet enough waves to fill the machine
+  const long long slots = (total + kTileCounters - 1) / kTileCounters;
+  int n_chunks = int(std::min<long long>(kCompactChunks, std::max<long long>(1, total / (64 * 8192))));
+  const long long waves = ((slots + 64 * n_chunks - 1) / (64 * n_chunks)) * kTileCounters;
+  const dim3 grid(unsigned((waves + kCompactThreads / 64 - 1) / (kCompactThreads / 64)));
   const uint32_t* occ = reinterpret_cast<const uint32_t*>(ctx->d_chunk) + kTileCounters * 32;
   if (ctx->last.occ_valid)
-    hipLaunchKernelGGL(rt_compact_tiles_kernel<false>, grid, dim3(256), 0, ctx->stream, slab, g, occ, ctx->last.occ_words,
-                       entries, count_dev, (unsigned int)capacity_tiles);
+    hipLaunchKernelGGL(rt_compact_tiles_kernel<false>, grid, dim3(kCompactThreads), 0, ctx->stream, slab, g, occ, ctx->last.occ_words,
+                       entries, count_dev, (unsigned int)capacity_tiles, n_chunks);
   else
-    hipLaunchKernelGGL(rt_compact_tiles_kernel<true>, grid, dim3(256), 0, ctx->stream, slab, g, (const uint32_t*)nullptr, 0,
-                       entries, count_dev, (unsigned int)capacity_tiles);
+    hipLaunchKernelGGL(rt_compact_tiles_kernel<true>, grid, dim3(kCompactThreads), 0, ctx->stream, slab, g, (const uint32_t*)nullptr, 0,
+                       entries, count_dev, (unsigned int)capacity_tiles, n_chunks);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -1191,9 +1197,16 @@ int rt_place_tiles(rt_ctx* ctx, const uint8_t* entries, const uint32_t* counts_d
   const long long row_bytes = (long long)width * 3;
   int vec4 = (row_bytes % 4 == 0) && (reinterpret_cast<uintptr_t>(out_rgb) % 4 == 0) && (reinterpret_cast<uintptr_t>(entries) % 4 == 0);
   if (vec4 && row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out_rgb) % 16 == 0) vec4 = 2;   // 16-byte stores
-  // (the fast path gives a lane 16-byte columns of a band: 128 lanes take a 1080p row's 360 columns in three turns)
+  // (the fast path gives a lane 16-byte columns of a band: as few turns as workgroups of up to 384 lanes need, and lanes to match
+  // — a 1080p row's 360 columns in one turn of 384; three turns of 128 measured 9 % slower: each turn waits for its table
+  // look-ups and then for its tiles)
+  unsigned place_threads = 256;
+  if (vec4 == 2 && (tile_rows & 7) == 0) {
+    const long long cols = row_bytes / 16, turns = (cols + 383) / 384;
+    place_threads = unsigned(std::min<long long>(384, ((cols + turns - 1) / turns + 63) / 64 * 64));
+  }
   hipLaunchKernelGGL(rt_place_tiles_kernel, dim3(unsigned((height + 7) / 8), unsigned(n_frames)),
-                     dim3((vec4 == 2 && (tile_rows & 7) == 0) ? 128 : 256), 0, ctx->stream, entries, (const uint32_t*)table, capacity_tiles, ids_per_rank, n_ranks, width, height,
+                     dim3(place_threads), 0, ctx->stream, entries, (const uint32_t*)table, capacity_tiles, ids_per_rank, n_ranks, width, height,
                      tile_rows, out_rgb, vec4);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;

@@ -113,64 +113,126 @@ struct TileGeom {          // the slab of one rank: n_frames windows of n_rows x
   int nx, n_rows, n_frames, tiles8_x, tiles8_y, tile_pitch;
   long long frame_stride_px;
 };
+// One wave looks at n_chunks (<= kCompactChunks) x 64 tile ids OF ONE COUNTER h (ids slot * 32 + h, consecutive slots): their occupancy
+// bits are consecutive bits of row h of `occ` — two scalar dwords per 64 ids, no per-lane look-up.  A workgroup of four waves
+// reserves room for all its kept tiles with ONE atomic.  (Round 3.  Before: one lane per consecutive id — a 32-line gather
+// per wave — and one atomic per wave; 130 000 atomics on one address took 0.66 ms per 256 1080p frames, five times what the
+// copy takes.  Sixteen waves per workgroup: fewer atomics still, but the barrier then holds them for the slowest.)
+#ifndef RT_COMPACT_CHUNKS
+#define RT_COMPACT_CHUNKS 16
+#endif
+#ifndef RT_COMPACT_AT_ONCE
+#define RT_COMPACT_AT_ONCE 4
+#endif
+constexpr int kCompactThreads = 256, kCompactChunks = RT_COMPACT_CHUNKS;
 template <bool SCAN>
-__global__ __launch_bounds__(256) void rt_compact_tiles_kernel(const uint8_t* __restrict__ slab, TileGeom g,
+__global__ __launch_bounds__(kCompactThreads) void rt_compact_tiles_kernel(const uint8_t* __restrict__ slab, TileGeom g,
                                                                const uint32_t* __restrict__ occ, int occ_words,
                                                                uint8_t* __restrict__ entries, unsigned int* __restrict__ count,
-                                                               unsigned int capacity) {
-  const int lane = threadIdx.x & 63;
-  const long long total = (long long)g.tile_pitch * g.tiles8_y * g.n_frames;
-  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int per_frame = g.tile_pitch * g.tiles8_y;
-  bool keep = false;
-  int frame = 0, ty = 0, tx = 0;
-  if (id < total) {
+                                                               unsigned int capacity, int n_chunks) {
+  constexpr int kWaves = kCompactThreads / 64;
+  __shared__ unsigned long long masks[kWaves][kCompactChunks];
+  __shared__ unsigned int wave_count[kWaves + 1];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const uint32_t total = uint32_t(g.tile_pitch) * uint32_t(g.tiles8_y) * uint32_t(g.n_frames);   // (< 2^31: the host checks)
+  const uint32_t per_frame = uint32_t(g.tile_pitch * g.tiles8_y);
+  const uint32_t gw = uint32_t(blockIdx.x) * kWaves + uint32_t(wave);
+  const uint32_t h = gw % kTileCounters, slot_base = (gw / kTileCounters) * (64u * uint32_t(n_chunks));
+  // where tile id `id` lies (the odd pitch leaves padding ids without a tile: tx >= tiles8_x)
+  auto where = [&](uint32_t id, int& frame, int& ty, int& tx) {
     frame = int(id / per_frame);
-    const int rem = int(id - (long long)frame * per_frame);
-    ty = rem / g.tile_pitch; tx = rem - ty * g.tile_pitch;
-    if (tx < g.tiles8_x) {                                   // (the odd pitch leaves padding ids without a tile)
+    const uint32_t rem = id - uint32_t(frame) * per_frame;
+    ty = int(rem / uint32_t(g.tile_pitch)); tx = int(rem) - ty * g.tile_pitch;
+  };
+  unsigned int mine = 0u;
+  for (int c = 0; c < n_chunks; ++c) {
+    const uint32_t slot0 = slot_base + 64u * uint32_t(c);
+    unsigned long long m = 0ull;
+    if (slot0 * kTileCounters + h < total) {                 // (wave-uniform: the chunk's first id exists)
       if constexpr (SCAN) {
-        const int rows = min(8, g.n_rows - ty * 8), nbytes = min(8, g.nx - tx * 8) * 3;
-        const uint8_t* src = slab + ((long long)frame * g.frame_stride_px + (long long)(ty * 8) * g.nx + tx * 8) * 3;
-        unsigned int any = 0u;
-        for (int r = 0; r < rows; ++r)
-          for (int b = 0; b < nbytes; ++b) any |= src[(long long)r * g.nx * 3 + b];
-        keep = any != 0u;
+        const uint32_t id = (slot0 + uint32_t(lane)) * kTileCounters + h;
+        bool keep = false;
+        if (id < total) {
+          int frame, ty, tx;
+          where(id, frame, ty, tx);
+          if (tx < g.tiles8_x) {
+            const int rows = min(8, g.n_rows - ty * 8), nbytes = min(8, g.nx - tx * 8) * 3;
+            const uint8_t* src = slab + ((long long)frame * g.frame_stride_px + (long long)(ty * 8) * g.nx + tx * 8) * 3;
+            unsigned int any = 0u;
+            for (int r = 0; r < rows; ++r)
+              for (int b = 0; b < nbytes; ++b) any |= src[(long long)r * g.nx * 3 + b];
+            keep = any != 0u;
+          }
+        }
+        m = __ballot(keep);
       } else {
-        const uint32_t slot = uint32_t(id) / kTileCounters, h = uint32_t(id) % kTileCounters;
-        keep = (occ[size_t(h) * size_t(occ_words) + (slot >> 5)] >> (slot & 31u)) & 1u;
+        const uint32_t* row = occ + size_t(h) * size_t(occ_words) + (slot0 >> 5);      // (wave-uniform: scalar loads)
+        m = (unsigned long long)row[0] | ((unsigned long long)row[1] << 32);          // (occ_words has a spare word)
+        // (bits of ids at or beyond `total` are never set: the visibility pass marks tiles that exist)
       }
     }
+    if (lane == 0) masks[wave][c] = m;
+    mine += (unsigned int)__popcll(m);
   }
-  const unsigned long long kept = __ballot(keep);
-  if (kept == 0ull) return;
-  unsigned int base = 0u;
-  if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(kept));
-  base = __builtin_amdgcn_readfirstlane(base);
+  if (lane == 0) wave_count[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int sum = 0u;
+    for (int w = 0; w < kWaves; ++w) { const unsigned int n = wave_count[w]; wave_count[w] = sum; sum += n; }
+    wave_count[kWaves] = sum ? atomicAdd(count, sum) : 0u;
+  }
+  __syncthreads();
+  if (mine == 0u) return;
+  const unsigned int base = __builtin_amdgcn_readfirstlane(wave_count[kWaves] + wave_count[wave]);
   const bool dwords = (g.nx & 3) == 0 && (g.frame_stride_px & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 3) == 0;
-  unsigned long long todo = kept;
+  const int r48 = (lane * 43) >> 8, w48 = lane - 6 * r48;    // lane l < 48: dword w of tile row r
   int k = 0;
-  while (todo != 0ull) {                                     // the wave copies its kept tiles one after another
-    const int src_lane = __ffsll((long long)todo) - 1;
-    todo &= todo - 1ull;
-    const unsigned int slot = base + unsigned(k++);
-    if (slot >= capacity) continue;                          // (the count still says how many there were: the host checks)
-    const int f = __builtin_amdgcn_readlane(frame, src_lane), y0 = __builtin_amdgcn_readlane(ty, src_lane) * 8,
-              x0 = __builtin_amdgcn_readlane(tx, src_lane) * 8;
-    const unsigned int tid = unsigned(__builtin_amdgcn_readlane(int(uint32_t(id)), src_lane));
-    uint8_t* e = entries + size_t(slot) * kTileEntryBytes;
-    if (lane == 0) *reinterpret_cast<uint32_t*>(e) = tid;
-    const uint8_t* src = slab + ((long long)f * g.frame_stride_px + (long long)y0 * g.nx + x0) * 3;
-    const int rows = min(8, g.n_rows - y0), cols = min(8, g.nx - x0);
-    if (dwords && cols == 8) {
-      const int r = (lane * 43) >> 8, w = lane - 6 * r;     // lane l < 48: dword w of tile row r
-      if (lane < 48)
-        reinterpret_cast<uint32_t*>(e + 4)[lane] =
-            r < rows ? *reinterpret_cast<const uint32_t*>(src + (long long)r * g.nx * 3 + w * 4) : 0u;
-    } else {
-      for (int b = lane; b < 192; b += 64) {
-        const int r = b / 24, c = b - 24 * r;
-        e[4 + b] = (r < rows && c < cols * 3) ? src[(long long)r * g.nx * 3 + c] : uint8_t(0);
+  for (int c = 0; c < n_chunks; ++c) {
+    unsigned long long todo = masks[wave][c];
+    todo = ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(todo >> 32)))) << 32) |
+           (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(todo))));
+    if (todo == 0ull) continue;
+    const uint32_t id = (slot_base + 64u * uint32_t(c) + uint32_t(lane)) * kTileCounters + h;
+    int frame, ty, tx;
+    where(id, frame, ty, tx);
+    // The wave copies the chunk's kept tiles FOUR at a time: four loads are in flight before the first store waits for its own.
+    constexpr int kAtOnce = RT_COMPACT_AT_ONCE;
+    while (todo != 0ull) {
+      uint32_t val[kAtOnce];
+      uint8_t* dst[kAtOnce];
+      unsigned int ids[kAtOnce];
+      bool fast[kAtOnce];
+#pragma unroll
+      for (int u = 0; u < kAtOnce; ++u) {
+        fast[u] = false; val[u] = 0u; dst[u] = nullptr; ids[u] = 0u;
+        if (todo == 0ull) continue;                            // (wave-uniform)
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const unsigned int slot = base + unsigned(k++);
+        if (slot >= capacity) continue;                        // (the count still says how many there were: the host checks)
+        const int f = __builtin_amdgcn_readlane(frame, src_lane), y0 = __builtin_amdgcn_readlane(ty, src_lane) * 8,
+                  x0 = __builtin_amdgcn_readlane(tx, src_lane) * 8;
+        ids[u] = unsigned(__builtin_amdgcn_readlane(int(id), src_lane));
+        uint8_t* e = entries + size_t(slot) * kTileEntryBytes;
+        dst[u] = e;
+        const uint8_t* src = slab + ((long long)f * g.frame_stride_px + (long long)y0 * g.nx + x0) * 3;
+        const int rows = min(8, g.n_rows - y0), cols = min(8, g.nx - x0);
+        if (dwords && cols == 8) {
+          fast[u] = true;
+          if (lane < 48 && r48 < rows) val[u] = *reinterpret_cast<const uint32_t*>(src + (long long)r48 * g.nx * 3 + w48 * 4);
+        } else {
+          if (lane == 0) *reinterpret_cast<uint32_t*>(e) = ids[u];
+          for (int b = lane; b < 192; b += 64) {
+            const int r = b / 24, cc = b - 24 * r;
+            e[4 + b] = (r < rows && cc < cols * 3) ? src[(long long)r * g.nx * 3 + cc] : uint8_t(0);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kAtOnce; ++u) {
+        if (!fast[u]) continue;                                // (wave-uniform)
+        if (lane == 0) *reinterpret_cast<uint32_t*>(dst[u]) = ids[u];
+        if (lane < 48) reinterpret_cast<uint32_t*>(dst[u] + 4)[lane] = val[u];
       }
     }
   }
@@ -192,7 +254,7 @@ __global__ __launch_bounds__(256) void rt_index_tiles_kernel(const uint8_t* __re
 // tile_rows (rt_render_rows); the 24 bytes of an 8-pixel segment come from row (local row mod 8) of the entry of
 // the rank's tile (local row / 8, x / 8).  A workgroup writes a band of 8 image rows of one frame, a thread one
 // dword of a row at a time (bytes when rows are not dword-aligned): consecutive lanes, consecutive addresses.
-__global__ __launch_bounds__(256) void rt_place_tiles_kernel(const uint8_t* __restrict__ entries, const uint32_t* __restrict__ table,
+__global__ __launch_bounds__(384) void rt_place_tiles_kernel(const uint8_t* __restrict__ entries, const uint32_t* __restrict__ table,
                                                              int capacity, long long ids_per_rank, int n_ranks, int width, int height,
                                                              int tile_rows, uint8_t* __restrict__ out, int vec4) {
   const int frame = blockIdx.y;
