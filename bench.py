@@ -270,6 +270,14 @@ def main():
             else:
                 comm_note += " — rt_comm_* failed its self-test on some rank"
 
+    # Row tiles at N >= 3: GPU 0 does not render.  It writes every byte of every frame (rt_place_tiles: 0.56 ms per 256 1080p
+    # frames whatever N) and that does not hide behind its own render — the shading kernel fills the register file, a
+    # kernel of another stream runs behind it, not beside it (tools/root_emulation.py) — so a root with a full share is the
+    # slowest rank from N = 3 on.  N - 1 ranks render tile t -> rank 1 + t mod (N - 1); the root gathers and places.
+    root_renders = world < 3
+    if os.environ.get("RT_BENCH_ROOT_RENDERS") in ("0", "1"):
+        root_renders = os.environ["RT_BENCH_ROOT_RENDERS"] == "1" or world == 1
+
     def measure(wl, F, B, steps, warmup, samples):
         """warmup + `steps` timed steps (of B batches of F frames) of workload `wl`; returns the numbers of the JSON line
         (rank 0) or None."""
@@ -278,9 +286,12 @@ def main():
         packed = pack_scene(build_scene(wl))
         r.upload_scene(packed)
         frame_parallel = wl == "c5" and world > 1           # BASELINE config 5: frame f -> rank f mod N, whole frames
-        rows_max = h if frame_parallel else tiling.max_local_rows(h, tr, world)
+        G = world if (root_renders or frame_parallel) else world - 1        # ranks that render row tiles
+        ridx = rank if (root_renders or frame_parallel) else rank - 1       # this rank's place among them (-1: none)
+        renders_here = ridx >= 0
+        rows_max = h if frame_parallel else tiling.max_local_rows(h, tr, G)
         slab_bytes = rows_max * w * 3
-        key = (w, h, F, frame_parallel)
+        key = (w, h, F, frame_parallel, G)
         if buffers.get("key") != key:
             buffers.clear()
             buffers["key"] = key
@@ -296,17 +307,18 @@ def main():
                 fo = buffers.get("frames_out")
                 if os.environ.get("RT_BENCH_DENSE"):
                     buffers["ex"] = BatchExchange(F, slab_bytes, dev,
-                                                  lambda gathered, i: r.scatter_rows_frames(gathered, world, w, h, tr, out=fo))
+                                                  lambda gathered, i: r.scatter_rows_frames(gathered[world - G:], G, w, h, tr, out=fo))
                 else:
                     table = {}
 
                     def place_tiles(entries, counts, i):
                         # (RCCL: called with the exchange's side stream current — the placement runs beside later renders)
-                        table["t"] = r.place_tiles(entries, counts, w, h, tr, fo, table.get("t"),
+                        # (a root that does not render has no entries: the renderers' are ranks 1 .. N - 1 of the gather)
+                        table["t"] = r.place_tiles(entries[world - G:], counts[world - G:], w, h, tr, fo, table.get("t"),
                                                    on_current_stream=buffers["ex"].on_side)
                     buffers["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
                                                   capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
-                                                  force_collectives=force_exchange, comm=comm)
+                                                  force_collectives=force_exchange, comm=comm, contributes=renders_here)
         ex = buffers.get("ex")
         frames_out = buffers.get("frames_out")
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -324,13 +336,15 @@ def main():
                 j = i * B + b
                 if timed_idx is not None and b == 0:
                     ev[timed_idx][0].record()
-                if frame_parallel:                  # this rank's frames of the batch, whole
+                if not renders_here:                # (the root at N >= 3: it gathers and places)
+                    pass
+                elif frame_parallel:                  # this rank's frames of the batch, whole
                     r.render_frames(cams, [j * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=frames_out)
                 else:
                     # N = 1: the rank owns every row, so its packed slab IS the frame batch
                     out = frames_out if ex is None else ex.slab(j).view(F, rows_max, w, 3)
                     r.render_frames(cams, range(j * F, (j + 1) * F), w, h, samples, max_depth=D, rng_mode="K",
-                                    out=out, tile_rows=tr, tile_first=rank, tile_stride=world)
+                                    out=out, tile_rows=tr, tile_first=ridx, tile_stride=G)
                 if timed_idx is not None and b == B - 1:
                     ev[timed_idx][1].record()
                 if ex is not None:
@@ -378,20 +392,23 @@ def main():
         launches_per_step = B * -(-n_local_frames // per_launch) * (1 if one_stream_launch else samples)
         # (with several batches per step the events also cover the other stream-ordered work between the pairs: the
         # exchange's compaction kernels at N > 1)
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (steps * launches_per_step)
-        kmax = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev)
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (steps * launches_per_step) if renders_here else 0.0
+        # (launch time, rays and shaded hits of the busiest rank: what the per-launch figures of the roofline block are about —
+        # rank 0's own where it renders alone)
+        kmax = torch.tensor([kern_ms, rc["total"], rc["shaded_hits"]], dtype=torch.float64, device=red_dev)
         if world > 1:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         if rank != 0:
             return None
+        kern_ms, rank_rays, rank_shaded = (float(x) for x in kmax.tolist())
         total_rays, shaded, primary = (float(x) for x in stats.tolist())
         dt = float(tmax.item())
         launches = steps * launches_per_step
         secs = kern_ms * 1e-3
         # per-launch (per rank) algorithmic flops of the launch pair on rank 0
-        fl = algorithmic_flops(rc["total"], rc["shaded_hits"], n_sph, packed.area_samples) / launches
+        fl = algorithmic_flops(rank_rays, rank_shaded, n_sph, packed.area_samples) / launches
         roof = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "frac_is": "EXECUTED: FP32 flops the VALUs retired (PMC SQ_INSTS_VALU_{ADD,MUL,TRANS}_F32 + 2 x FMA_F32, x 64 lanes: "
                            "a full-wave upper bound; per-ray counts of the committed profile `pmc_profile` of this workload, scaled "
@@ -409,7 +426,7 @@ def main():
         pmc = PMC.get(wl)
         if pmc and samples == 1 and args.kernel == "stream" and not os.environ.get("RT_BENCH_NO_TILE_FLUSH"):
             # what the hardware executed: the profiled launch pair's counts per ray x this run's rays per launch
-            scale = (rc["total"] / launches) / pmc["rays"]
+            scale = (rank_rays / launches) / pmc["rays"]
             roof["achieved"] = pmc["flops"] * scale / secs / 1e12
             roof["frac"] = roof["achieved"] / PEAK_FP32_TFLOPS
             roof["executed_flops_per_launch"] = pmc["flops"] * scale
@@ -424,7 +441,8 @@ def main():
         if frame_parallel:
             par = f"frame-parallel x{world}: frame f -> rank f mod {world}, whole frames, one gather after the timed region"
         elif world > 1 or ex is not None:
-            par = f"row-tiles x{world} (tile {tr} rows) + RCCL gather to GPU 0" + \
+            par = f"row-tiles x{G} (tile {tr} rows" + ("" if G == world else f"; GPU 0 of {world} gathers and places, it does not render") + \
+                  ") + RCCL gather to GPU 0" + \
                   (" of the occupied 8x8 tiles" if ex is not None and ex.sparse else "") + \
                   (" (a group of ONE rank: rehearsal of the N > 1 step)" if world == 1 else "")
         else:

@@ -15,6 +15,7 @@ gloo.
 """
 from __future__ import annotations
 
+import os
 import numpy as np
 
 from .tiling import DEFAULT_TILE_ROWS, local_rows, max_local_rows
@@ -97,10 +98,15 @@ class BatchExchange:
     With RCCL (device tensors, backend nccl) nothing of the exchange is queued on the render stream: the counts of a
     batch are copied to pinned host memory on a SIDE stream that waits for the count exchange alone, and the host reads
     them after an event there — not after the renders it has queued since —; the gather is issued from the side stream
-    (RCCL's stream then waits for that batch's compaction, not for later renders), and the root's placement runs there
-    too, beside its own render (``place_tiles`` is called with the side stream current and must launch on it).  The
+    (RCCL's stream then waits for that batch's compaction, not for later renders); the root's placement runs there too, or —
+    where the root renders itself — on the render stream once the gather has landed (see ``place_beside``;
+    ``place_tiles`` is called with the stream it must launch on current).  The
     render stream only waits, three batches later, for the gather that read the entry buffer it is about to overwrite.
     ``force_collectives``: a group of one rank still goes through every collective (the one-GPU rehearsal of this path).
+    ``contributes`` False (sparse mode): this rank rendered nothing — a root that only gathers and places (bench.py from three
+    GPUs on) —: it joins every collective with a count of zero and ``compact`` is not called.
+    ``place_beside``: True = the root's placement runs on the side stream, False = on the render stream once the gather has
+    landed; default: beside only where the root does not render (``contributes`` False).
     ``comm``: a Renderer that holds a communicator (Renderer.comm_init): the two collectives of the sparse exchange are
     then the library's (rt_comm_all_gather_counts, rt_comm_gather — every rank sends exactly its own entries, nothing is
     padded to the largest rank), issued on the side stream; torch.distributed makes no call on the data path.
@@ -108,13 +114,18 @@ class BatchExchange:
 
     def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0, *,
                  compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196,
-                 force_collectives: bool = False, comm=None):
+                 force_collectives: bool = False, comm=None, contributes: bool = True, place_beside: bool | None = None):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.comm = comm
+        self.contributes = bool(contributes)
+        # where the root's placement runs (RCCL path): beside the renders, on the side stream — or, by default where the root
+        # renders too, on the render stream behind the gather: measured, a placement that competes with the root's own shading
+        # kernel costs more than it hides (tools/root_emulation.py: config 4 at N = 2 6.1 ms per batch beside, 5.2 behind)
+        self.place_beside = (not self.contributes) if place_beside is None else bool(place_beside)
         if comm is not None:
             info = comm.comm_info()
             if compact is None or torch.device(device).type != "cuda":
@@ -138,7 +149,12 @@ class BatchExchange:
             self.capacity = int(capacity)
             self.gathered = [None, None]
             if self.on_side:
-                self.side = torch.cuda.Stream(device=device)
+                # High priority: HIP gives such a stream a hardware queue of its own class.  A stream of normal priority can be
+                # handed the hardware queue the render stream uses (GPU_MAX_HW_QUEUES = 4, dealt round-robin) — then gather and
+                # placement queue up BEHIND the renders instead of running beside them (seen in a kernel trace: both on queue 4,
+                # strictly one after the other).  And a placement is short, memory-bound work that should not wait for a
+                # persistent shading kernel to drain.
+                self.side = torch.cuda.Stream(device=device, priority=int(os.environ.get("RT_EXCHANGE_STREAM_PRIORITY", "-1")))
                 self.counts_all = [torch.zeros(self.world, dtype=torch.int32, device=device) for _ in range(3)]
                 self.counts_host = [torch.zeros(self.world, dtype=torch.int32).pin_memory() for _ in range(3)]
                 self.reusable = [None, None, None]   # event on the side stream: the gather that read entries[b] is done
@@ -197,7 +213,10 @@ class BatchExchange:
         if self.on_side and self.reusable[b3] is not None:
             torch.cuda.current_stream().wait_event(self.reusable[b3])   # the gather of batch step - 3 has read entries[b3]
             self.reusable[b3] = None
-        self.compact(self.slabs[step & 1], self.entries[b3], self.count[b3])
+        if self.contributes:
+            self.compact(self.slabs[step & 1], self.entries[b3], self.count[b3])
+        else:
+            self.count[b3].zero_()               # (a rank that rendered nothing — a root that only places — joins with no entries)
         st = dict(b3=b3, counts=None, work=None, nmax=None, gathered=None, ready=None)
         if not self.collectives:
             st["counts"] = self.count[b3]
@@ -282,14 +301,23 @@ class BatchExchange:
         self._gather_stage(step)
         if self.on_side:
             import torch
+            behind = self.rank == self.dst and not self.place_beside
             with torch.cuda.stream(self.side):
                 if st["work"] is not None:
                     st["work"].wait()
-                if self.rank == self.dst:
+                if self.rank == self.dst and not behind:
                     self.place_tiles(st["gathered"], st["counts"], step)
                 # entries[b3] (read by the gather) and counts_all[b3] (read by the placement) may be written again after this
-                self.reusable[st["b3"]] = torch.cuda.Event()
-                self.reusable[st["b3"]].record()
+                done = torch.cuda.Event()
+                done.record()
+            if behind:                                # on the render stream, once the gather has landed
+                main = torch.cuda.current_stream()
+                main.wait_event(done)
+                st["gathered"].record_stream(main)    # (allocated on the side stream)
+                self.place_tiles(st["gathered"], st["counts"], step)
+                done = torch.cuda.Event()
+                done.record()
+            self.reusable[st["b3"]] = done
             del self.stage[step]
             return
         if st["work"] is not None:

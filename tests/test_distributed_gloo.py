@@ -59,7 +59,7 @@ def test_gather_row_tiles_gloo(world, w, h, tile_rows):
     assert ok and frames_ok and (nonblack or h < 8)
 
 
-def _sparse_exchange_worker(rank, world, port, q):
+def _sparse_exchange_worker(rank, world, port, q, root_places_only=False):
     """BatchExchange's sparse pipeline on CPU tensors: mostly black slabs with a different number of lit tiles on
     every rank and step (also none at all); compact / place_tiles are the numpy stand-ins of tests/tile_exchange_ref
     (the HIP entry points need a GPU: tests below)."""
@@ -72,8 +72,11 @@ def _sparse_exchange_worker(rank, world, port, q):
         from raytracer_amd import tiling
         from raytracer_amd.distributed import BatchExchange
         F, w, h, tr, steps = 3, 40, 37, 8, 7
-        rows_max = tiling.max_local_rows(h, tr, world)
-        n_rows = tiling.local_row_count(h, tr, rank, world)
+        # (root_places_only: bench.py's layout from three GPUs on — ranks 1 .. world - 1 render the row tiles of a group of
+        # world - 1, rank 0 joins every collective with no entries and places the others')
+        G, ridx = (world - 1, rank - 1) if root_places_only else (world, rank)
+        rows_max = tiling.max_local_rows(h, tr, G)
+        n_rows = tiling.local_row_count(h, tr, ridx, G) if ridx >= 0 else 0
 
         def frames_of(step):
             g = np.random.default_rng(100 + step)
@@ -86,7 +89,7 @@ def _sparse_exchange_worker(rank, world, port, q):
             return fr
 
         def slab_of(step, r):
-            rows = tiling.local_rows(h, tr, r, world)
+            rows = tiling.local_rows(h, tr, r, G)
             sl = np.zeros((F, rows_max, w, 3), np.uint8)
             sl[:, :len(rows)] = frames_of(step)[:, rows]
             if step == 4 and r == 0:
@@ -101,17 +104,20 @@ def _sparse_exchange_worker(rank, world, port, q):
         placed = []
 
         def place_tiles(entries, counts, step):
-            got = ref.place(entries.numpy(), counts.numpy(), F, w, h, tr)
+            if root_places_only:
+                assert int(counts[0]) == 0
+            got = ref.place(entries[world - G:].numpy(), counts[world - G:].numpy(), F, w, h, tr)
             exp = frames_of(step)
             if step == 4:
-                exp[:, tiling.local_rows(h, tr, 0, world)] = 0
+                exp[:, tiling.local_rows(h, tr, 0, G)] = 0
             placed.append((step, bool(np.array_equal(got, exp))))
 
         ex = BatchExchange(F, rows_max * w * 3, "cpu", None, compact=compact, place_tiles=place_tiles,
-                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8))
+                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), contributes=ridx >= 0)
         assert ex.sparse
         for i in range(steps):
-            ex.slab(i).copy_(torch.from_numpy(slab_of(i, rank)).view(F, -1))
+            if ridx >= 0:
+                ex.slab(i).copy_(torch.from_numpy(slab_of(i, ridx)).view(F, -1))
             ex.submit(i)
         ex.drain()
         assert ex.sent_bytes < steps * F * rows_max * w * 3 / 2      # (dense: the whole slabs)
@@ -165,14 +171,15 @@ def test_batch_exchange_pipeline_gloo(world):
     assert [s for s, _ in placed] == list(range(7)) and all(ok for _, ok in placed)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sparse_batch_exchange_gloo(world):
+@pytest.mark.parametrize("world,root_places_only", [(2, False), (3, False), (3, True)])
+def test_sparse_batch_exchange_gloo(world, root_places_only):
     """BatchExchange's sparse mode: only occupied tiles travel, three pipelined stages; the root assembles the
-    same frames."""
+    same frames — also where it renders nothing itself (bench.py's layout from three GPUs on: the other ranks share the
+    row tiles, rank 0 joins with no entries)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, world, port, q, root_places_only)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -193,7 +200,7 @@ def test_batch_exchange_single_process():
     assert seen == [(0, (1, 2, 8), 1), (1, (1, 2, 8), 2), (2, (1, 2, 8), 3)]
 
 
-def _gpu_exchange_worker(rank, world, port, q, sparse=False, glass=False):
+def _gpu_exchange_worker(rank, world, port, q, sparse=False, glass=False, root_places_only=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -205,7 +212,9 @@ def _gpu_exchange_worker(rank, world, port, q, sparse=False, glass=False):
         w, h, tr, F, steps = 320, 187, 8, 5, 4
         r = Renderer(0)
         r.upload_scene(refractive_scene() if glass else generate_scene(8, 1, keep_default=True))
-        rows_max = tiling.max_local_rows(h, tr, world)
+        # (root_places_only: bench.py's layout from three GPUs on — ranks 1 .. world - 1 share the row tiles, rank 0 places)
+        G, ridx = (world - 1, rank - 1) if root_places_only else (world, rank)
+        rows_max = tiling.max_local_rows(h, tr, G)
         frames_out = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0")
         ok = []
 
@@ -219,22 +228,23 @@ def _gpu_exchange_worker(rank, world, port, q, sparse=False, glass=False):
                 ok.append(bool(torch.equal(frames_out, full)))
 
         def place(gathered, i):          # rank 0: assemble batch i and compare it with whole-frame renders
-            r.scatter_rows_frames(gathered, world, w, h, tr, out=frames_out)
+            r.scatter_rows_frames(gathered[world - G:], G, w, h, tr, out=frames_out)
             check(i)
 
         def place_tiles(entries, counts, i):   # sparse: the HIP placement kernel (black + tiles in one pass)
             frames_out.fill_(77)
-            r.place_tiles(entries, counts, w, h, tr, frames_out)
+            r.place_tiles(entries[world - G:], counts[world - G:], w, h, tr, frames_out)
             check(i)
 
         ex = BatchExchange(F, rows_max * w * 3, "cuda:0", place, compact=r.compact_tiles, place_tiles=place_tiles,
-                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8)) if sparse else \
+                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), contributes=ridx >= 0) if sparse else \
             BatchExchange(F, rows_max * w * 3, "cuda:0", place)
         assert ex.sparse == bool(sparse)
         for i in range(steps):
             cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
-            r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=ex.slab(i).view(F, rows_max, w, 3),
-                            tile_rows=tr, tile_first=rank, tile_stride=world)
+            if ridx >= 0:
+                r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=ex.slab(i).view(F, rows_max, w, 3),
+                                tile_rows=tr, tile_first=ridx, tile_stride=G)
             ex.submit(i)
         ex.drain()
         if rank == 0:
@@ -256,6 +266,24 @@ def test_batch_exchange_of_gpu_row_tiles(world, sparse):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_gpu_exchange_worker, args=(r, world, port, q, sparse)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(170)
+        assert p.exitcode == 0
+    ok = q.get(timeout=5)
+    assert ok == [True] * 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_batch_exchange_with_a_root_that_only_places(sparse):
+    """bench.py's layout from three GPUs on: ranks 1 and 2 render the row tiles of a group of two, rank 0 renders nothing,
+    joins the collectives (with no entries in the sparse exchange) and places the others' tiles: byte-identical frames."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_exchange_worker, args=(r, 3, port, q, sparse, False, True)) for r in range(3)]
     for p in procs:
         p.start()
     for p in procs:

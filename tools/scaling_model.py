@@ -3,8 +3,9 @@
 rt_compact_tiles of its slab, the bytes a rank hands to the gather, and rt_place_tiles of all N ranks' entries on the root
 (every rank's share is rendered here, one after another, to have real entries).  Model of the steady state of the
 pipelined exchange (raytracer_amd/distributed.py): a batch leaves every
-    period(N) = max( render + compact [any rank],  bytes per rank / link rate [each peer has its own xGMI link into GPU 0],
-                     root: render + compact + place  [serial: the pessimistic end] or max(render + compact, place) [overlapped] )
+    period(N) = max( render + compact [a rank that renders],  bytes per rank / link rate [each peer has its own xGMI link into
+                     GPU 0],  root: render + compact + place [N = 2: the placement runs behind the root's own render], place alone
+                     [N >= 3: the root does not render; N - 1 ranks share the row tiles] )
     python tools/scaling_model.py [workloads...] > profiles/r3_scaling_model.txt"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -35,11 +36,12 @@ for wl in (sys.argv[1:] or ["c2", "t64", "c4"]):
     r.upload_scene(bench.build_scene(wl))
     cams = r.pack_cameras([Camera()] * F)
     print(f"## {wl}: {desc}; batches of {F} frames, row tiles of {tr} rows")
-    print("| N | render share ms | compact ms | occupied tiles of rank 0 | MB per rank | link ms @153 GB/s | place ms (root) | period serial ms | "
-          "period overlapped ms | bound (serial / overlapped) | frames/s serial | frames/s overlapped | speed-up serial / overlapped |")
+    print("| N | ranks that render | render share ms | compact ms | occupied tiles of the first renderer | MB per rank | link ms @153 GB/s | "
+          "place ms (root) | renderers' period ms | root's period ms | bound | frames/s | speed-up |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     base = None
-    for G in (1, 2, 4, 8):
+    for N in (1, 2, 4, 8):
+        G = N if N < 3 else N - 1          # bench.py: from three GPUs on the root gathers and places, it does not render
         rows_max = tiling.max_local_rows(h, tr, G)
         cap = F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8)
         slabs = [torch.empty((F, rows_max, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(1)]
@@ -65,24 +67,18 @@ for wl in (sys.argv[1:] or ["c2", "t64", "c4"]):
         table = {}
         def place():
             table["t"] = r.place_tiles(gathered, counts, w, h, tr, out, table.get("t"))
-        t_place = timed(place) if G > 1 else 0.0
+        t_place = timed(place) if N > 1 else 0.0
         mb = nmax * TILE_ENTRY_BYTES / 1e6
-        t_link = mb / 1e3 / LINK_GBS * 1e3 if G > 1 else 0.0
-        if G == 1:
-            t_compact_eff = 0.0          # (a single GPU renders into the frames: no exchange)
-        else:
-            t_compact_eff = t_compact
-        work = t_render + t_compact_eff
-        serial = max(work, t_link, work + t_place)
-        overl = max(work, t_link, t_place)
-        def bound(per, root):
-            if per == t_link: return "link"
-            if per == root and root > work + 1e-9: return "root placement"
-            return "render"
-        fs_s, fs_o = F / serial * 1e3, F / overl * 1e3
-        if base is None: base = fs_s
-        print(f"| {G} | {t_render:.2f} | {t_compact:.2f} | {cnt[0]} | {mb:.1f} | {t_link:.2f} | {t_place:.2f} | {serial:.2f} | {overl:.2f} | "
-              f"{bound(serial, work + t_place)} / {bound(overl, t_place)} | {fs_s:.0f} | {fs_o:.0f} | {fs_s / base:.2f} / {fs_o / base:.2f} |")
+        t_link = mb / 1e3 / LINK_GBS * 1e3 if N > 1 else 0.0
+        work = t_render + (t_compact if N > 1 else 0.0)      # (a single GPU renders into the frames: no exchange)
+        root = work + t_place if G == N else t_place          # (placement behind the root's own render: tools/root_emulation.py)
+        period = max(work, t_link, root)
+        bound = "link" if period == t_link else "root (render + placement)" if (period == root and G == N and N > 1) else \
+                "root (placement)" if period == root and N > 1 else "render"
+        fs = F / period * 1e3
+        if base is None: base = fs
+        print(f"| {N} | {G} | {t_render:.2f} | {t_compact:.2f} | {cnt[0]} | {mb:.1f} | {t_link:.2f} | {t_place:.2f} | {work:.2f} | {root:.2f} | "
+              f"{bound} | {fs:.0f} | {fs / base:.2f} |")
         del slabs, entries, gathered, out
         torch.cuda.empty_cache()
     print()
