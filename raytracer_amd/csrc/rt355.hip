@@ -133,6 +133,13 @@ struct rt_ctx {
   int n_cubes = 0;
   unsigned long long* d_counters = nullptr;
   FrameRec* d_frames = nullptr;  // [kMaxBatch] cameras and seeds of the batch in flight
+  // batches of more than kFrameChunk frames: their records go up in ONE copy from a ring of pinned staging slots (an event
+  // per slot says when the copy that read it is done) instead of one tiny launch per 64 frames — sixteen launches, each with
+  // its gap, ahead of a 1024-frame batch
+  static constexpr int kFrameRing = 4;
+  FrameRec* h_frames = nullptr;  // [kFrameRing][kMaxBatch], pinned
+  hipEvent_t h_frames_ev[kFrameRing] = {};
+  int h_frames_next = 0;
   CamGroup* d_camtab = nullptr;  // [kMaxBatch][cam_groups_stride(n)] primary-ray tables
   int16_t* d_vis = nullptr;      // visibility pass output, [batch][window pixels] (grown on demand)
   unsigned long long* d_present = nullptr;   // samples in one stream launch: per tile, the samples that hit (grown on demand)
@@ -511,6 +518,19 @@ int launch(rt_ctx* ctx, const rt_camera* cams, const uint64_t* seeds, int n_fram
     const size_t lds = stream_kernel ? stream_lds(ctx->n_spheres + 2 * ctx->n_cubes, refr_kind, slots, wg_waves) : pixel_lds(ctx->n_spheres);
     p.n_frames = nf;
     p.frames = d_frames;
+    if (!ws && nf > kFrameChunk) {                   // cameras and seeds of a big batch -> device: one copy from pinned staging
+      const int slot = ctx->h_frames_next;
+      ctx->h_frames_next = (slot + 1) % rt_ctx::kFrameRing;
+      RT_HIP(ctx, hipEventSynchronize(ctx->h_frames_ev[slot]));   // (the copy that last read this slot: four batches ago)
+      FrameRec* h = ctx->h_frames + size_t(slot) * kMaxBatch;
+      for (int f = 0; f < nf; ++f) {
+        h[f].cam = cams[f0 + f];
+        h[f].seed = uint32_t(seeds[f0 + f] ^ (seeds[f0 + f] >> 32));
+        h[f].pad[0] = h[f].pad[1] = h[f].pad[2] = 0u;
+      }
+      RT_HIP(ctx, hipMemcpyAsync(d_frames, h, sizeof(FrameRec) * size_t(nf), hipMemcpyHostToDevice, ctx->stream));
+      RT_HIP(ctx, hipEventRecord(ctx->h_frames_ev[slot], ctx->stream));
+    } else
     for (int c0 = 0; c0 < nf; c0 += kFrameChunk) {   // cameras and seeds of the batch -> device (stream order
       FrameChunk chunk;                              // protects the previous batch's readers)
       const int nc = std::min(kFrameChunk, nf - c0);
@@ -743,6 +763,10 @@ int rt_create(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_glass_bits, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMalloc");
   if ((e = hipMemset(ctx->d_glass_bits, 0, sizeof(uint32_t) * (RT_MAX_SPHERES / 32))) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMalloc(&ctx->d_frames, sizeof(FrameRec) * kMaxBatch)) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_frames), sizeof(FrameRec) * kMaxBatch * rt_ctx::kFrameRing, hipHostMallocDefault)) != hipSuccess)
+    return bail(e, "hipHostMalloc");
+  for (int k = 0; k < rt_ctx::kFrameRing; ++k)
+    if ((e = hipEventCreateWithFlags(&ctx->h_frames_ev[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipMalloc(&ctx->d_camtab, sizeof(CamGroup) * size_t(cam_groups_stride(RT_MAX_SPHERES)) * kMaxBatch)) != hipSuccess)
     return bail(e, "hipMalloc");
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -781,6 +805,9 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+  if (ctx->h_frames) (void)hipHostFree(ctx->h_frames);
+  for (int k = 0; k < rt_ctx::kFrameRing; ++k)
+    if (ctx->h_frames_ev[k]) (void)hipEventDestroy(ctx->h_frames_ev[k]);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   if (ctx->d_spill) (void)hipFree(ctx->d_spill);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);

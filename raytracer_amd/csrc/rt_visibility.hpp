@@ -336,7 +336,16 @@ __global__ __launch_bounds__(RT_VIS_BLOCK, MANY ? RT_VIS_WAVES_MANY : RT_VIS_WAV
   constexpr int NT = kVisTiles;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.z;
-  const int col0 = (int(blockIdx.y) * (RT_VIS_BLOCK / 64) + wave) * (8 * NT), rowR = int(blockIdx.x) * (8 * kVisRows);   // window coordinates
+  // Which region row a workgroup takes.  Workgroups go to the 8 XCDs round-robin by linear id (x fastest), so with a number of
+  // region rows that is a multiple of 4 an XCD would see the same one or two region rows of every column and frame — and
+  // the rows through the spheres cost several times what the black ones do: 4 or 8 region rows (a rank's share at N = 7, 3,
+  // 6) ran 2x slower than 3, 5 or 7.  There the row is rotated by column and frame, so every XCD gets every row.
+  int region_row = int(blockIdx.x);
+  if ((gridDim.x & 3u) == 0u) {
+    region_row += int((blockIdx.y + blockIdx.z) & (gridDim.x >= 8u ? 7u : 3u));
+    if (region_row >= int(gridDim.x)) region_row -= int(gridDim.x);
+  }
+  const int col0 = (int(blockIdx.y) * (RT_VIS_BLOCK / 64) + wave) * (8 * NT), rowR = region_row * (8 * kVisRows);   // window coordinates
   if (p.nx - col0 <= 0) return;                           // wave-uniform: beyond the right edge
   constexpr bool region_kept = MANY;
   bool region_any = false;

@@ -6,7 +6,7 @@ pipelined exchange (raytracer_amd/distributed.py): a batch leaves every
     period(N) = max( render + compact [a rank that renders],  bytes per rank / link rate [each peer has its own xGMI link into
                      GPU 0],  root: render + compact + place [N = 2: the placement runs behind the root's own render], place alone
                      [N >= 3: the root does not render; N - 1 ranks share the row tiles] )
-    python tools/scaling_model.py [workloads...] > profiles/r3_scaling_model.txt"""
+    python tools/scaling_model.py [workloads...] [--frames F (per batch; default 256, config 4: F / 16)] > profiles/r3_scaling_model.txt"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -30,9 +30,11 @@ def timed(fn, reps=5):
     return min(ts[1:])
 
 
-for wl in (sys.argv[1:] or ["c2", "t64", "c4"]):
+FRAMES = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
+workloads = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--frames"]
+for wl in (workloads or ["c2", "t64", "c4"]):
     w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
-    F = 16 if wl == "c4" else 256
+    F = max(1, FRAMES // 16) if wl == "c4" else FRAMES
     r.upload_scene(bench.build_scene(wl))
     cams = r.pack_cameras([Camera()] * F)
     print(f"## {wl}: {desc}; batches of {F} frames, row tiles of {tr} rows")
