@@ -52,8 +52,8 @@ PY_REFERENCE_MRAYS = 0.036        # the Python reference itself, 1 
 # (TCC_EA0_WRREQ x 64 + TCC_EA0_RDREQ x 64 x 2, the guide's gfx950 correction), and the rays of that launch pair.
 # (tools/pmc_constants.py prints these lines from a tools/profile.sh directory.)
 PMC = {
-    "c2": dict(profile="profiles/r3z_c2_rt_{stream,visibility}_kernel.txt", flops=3.64e+11, valu=7.705e+09, salu=2.929e+09, hbm_bytes=1.069e+10, rays=7.863e+09),
-    "t64": dict(profile="profiles/r3z_t64_rt_{stream,visibility}_kernel.txt", flops=3.228e+11, valu=7.002e+09, salu=2.709e+09, hbm_bytes=1.164e+10, rays=6.428e+09),
+    "c2": dict(profile="profiles/r3z_c2_rt_{stream,visibility}_kernel.txt", flops=3.64e+11, valu=7.719e+09, salu=2.929e+09, hbm_bytes=1.069e+10, rays=7.863e+09),
+    "t64": dict(profile="profiles/r3z_t64_rt_{stream,visibility}_kernel.txt", flops=3.228e+11, valu=7.021e+09, salu=2.709e+09, hbm_bytes=1.164e+10, rays=6.428e+09),
     "c4": dict(profile="profiles/r3z_c4_rt_{stream,visibility}_kernel.txt", flops=2.724e+11, valu=5.175e+09, salu=1.348e+09, hbm_bytes=1.868e+10, rays=3.36e+09),
     "refr": dict(profile="profiles/r3z_refr_rt_{stream,visibility}_kernel.txt", flops=5.574e+11, valu=1.353e+10, salu=4.502e+09, hbm_bytes=1.144e+10, rays=9.619e+09),
     "cubes": dict(profile="profiles/r3z_cubes_rt_{stream,visibility}_kernel.txt", flops=7.309e+11, valu=1.769e+10, salu=5.734e+09, hbm_bytes=1.041e+10, rays=1.156e+10),
