@@ -8,8 +8,9 @@ BASELINE.json config 2 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per s
 index), inputs (scene) already resident on the GPU: 10 240 frames, ~125 ms per step, so that the default 20 timed steps
 last ~2.5 s and the clocks are at their steady state (a single batch takes 12 ms).  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
-(tile t -> rank t mod N), each rank renders its tiles of all frames of the batch, and ONE RCCL
-gather per step moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
+(tile t -> the (t mod G)-th of the G ranks that render: both at N = 2, ranks 1 .. N - 1 from three GPUs on, where GPU 0 only
+gathers and places — RT_BENCH_ROOT_RENDERS=0/1 overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
+gather per batch moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
 raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_place_tiles writes the frames in image order:
 total work per step is fixed => "strong" scaling.  ``--workload c5`` at N > 1 is BASELINE config 5's mode
 instead: frame f -> rank f mod N, whole frames, no exchange inside the timed region; the one gather at the end

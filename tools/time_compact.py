@@ -1,5 +1,6 @@
-"""GPU box: rt_compact_tiles and rt_place_tiles alone, on config 2's slabs of 256 frames at N = 1 and N = 8 (events, best of 5).
-    RT355_LIB=... python tools/time_compact.py"""
+"""GPU box: the exchange kernels alone, on config 2's slabs of 256 frames (events, best of 5): rt_compact_tiles of a whole-frame
+slab (N = 1) and of rank 0's eighth (N = 8); rt_place_tiles of eight ranks' entries, against a plain fill of the same frames
+and against the same call with no entries at all (every tile black).      RT355_LIB=... python tools/time_compact.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
