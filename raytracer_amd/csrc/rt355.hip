@@ -805,9 +805,9 @@ void rt_destroy(rt_ctx* ctx) {
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_camtab) (void)hipFree(ctx->d_camtab);
   if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+  for (int k = 0; k < rt_ctx::kFrameRing; ++k)      // (a copy out of the pinned ring may still be queued on a caller's stream)
+    if (ctx->h_frames_ev[k]) { (void)hipEventSynchronize(ctx->h_frames_ev[k]); (void)hipEventDestroy(ctx->h_frames_ev[k]); }
   if (ctx->h_frames) (void)hipHostFree(ctx->h_frames);
-  for (int k = 0; k < rt_ctx::kFrameRing; ++k)
-    if (ctx->h_frames_ev[k]) (void)hipEventDestroy(ctx->h_frames_ev[k]);
   if (ctx->d_accum) (void)hipFree(ctx->d_accum);
   if (ctx->d_spill) (void)hipFree(ctx->d_spill);
   if (ctx->d_vis) (void)hipFree(ctx->d_vis);
