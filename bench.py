@@ -8,8 +8,8 @@ BASELINE.json config 2 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per s
 index), inputs (scene) already resident on the GPU: 10 240 frames, ~125 ms per step, so that the default 20 timed steps
 last ~2.5 s and the clocks are at their steady state (a single batch takes 12 ms).  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
-(tile t -> the (t mod G)-th of the G ranks that render: both at N = 2, ranks 1 .. N - 1 from three GPUs on, where GPU 0 only
-gathers and places — RT_BENCH_ROOT_RENDERS=0/1 overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
+(tile t -> the (t mod G)-th of the G ranks that render: all N, or — in some batches of a fixed pattern, in all from five GPUs
+on — ranks 1 .. N - 1 while GPU 0 only gathers and places; RT_BENCH_LAYOUTS overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
 gather per batch moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
 raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_place_tiles writes the frames in image order:
 total work per step is fixed => "strong" scaling.  ``--workload c5`` at N > 1 is BASELINE config 5's mode
@@ -271,13 +271,23 @@ def main():
             else:
                 comm_note += " — rt_comm_* failed its self-test on some rank"
 
-    # Row tiles at N >= 3: GPU 0 does not render.  It writes every byte of every frame (rt_place_tiles: 0.56 ms per 256 1080p
-    # frames whatever N) and that does not hide behind its own render — the shading kernel fills the register file, a
-    # kernel of another stream runs behind it, not beside it (tools/root_emulation.py) — so a root with a full share is the
-    # slowest rank from N = 3 on.  N - 1 ranks render tile t -> rank 1 + t mod (N - 1); the root gathers and places.
-    root_renders = world < 3
+    # Row tiles at N > 1: which ranks render, batch by batch.  GPU 0 writes every byte of every frame (rt_place_tiles: 0.56 ms
+    # per 256 1080p frames whatever N) and that does not hide behind its own render — the shading kernel fills the register
+    # file, a kernel of another stream runs behind it, not beside it (tools/root_emulation.py) — so a root with a full share
+    # is the slowest rank.  Two layouts take turns in a fixed pattern, one letter per batch:
+    #   A — all N ranks render, tile t -> rank t mod N;      B — ranks 1 .. N - 1 render, tile t -> rank 1 + t mod (N - 1),
+    #                                                            the root gathers and places only.
+    # The pattern gives the root the share of rendering that its placement leaves room for (from the pieces measured by
+    # tools/scaling_model.py: 5 of 6 batches at N = 2, 2 of 3 at N = 3, every other one at N = 4, none from N = 5 on).  The
+    # exchange is asynchronous, batches deep, so what counts is each rank's work summed over a pattern, not batch by batch.
+    # RT_BENCH_LAYOUTS=<letters> overrides (RT_BENCH_ROOT_RENDERS=1 / 0: "A" / "B").
+    pattern = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"}.get(world, "B")
     if os.environ.get("RT_BENCH_ROOT_RENDERS") in ("0", "1"):
-        root_renders = os.environ["RT_BENCH_ROOT_RENDERS"] == "1" or world == 1
+        pattern = "A" if os.environ["RT_BENCH_ROOT_RENDERS"] == "1" else "B"
+    if os.environ.get("RT_BENCH_LAYOUTS"):
+        pattern = os.environ["RT_BENCH_LAYOUTS"].upper()
+    if world == 1 or set(pattern) - {"A", "B"} or not pattern:
+        pattern = "A"
 
     def measure(wl, F, B, steps, warmup, samples):
         """warmup + `steps` timed steps (of B batches of F frames) of workload `wl`; returns the numbers of the JSON line
@@ -287,41 +297,53 @@ def main():
         packed = pack_scene(build_scene(wl))
         r.upload_scene(packed)
         frame_parallel = wl == "c5" and world > 1           # BASELINE config 5: frame f -> rank f mod N, whole frames
-        G = world if (root_renders or frame_parallel) else world - 1        # ranks that render row tiles
-        ridx = rank if (root_renders or frame_parallel) else rank - 1       # this rank's place among them (-1: none)
-        renders_here = ridx >= 0
-        rows_max = h if frame_parallel else tiling.max_local_rows(h, tr, G)
-        slab_bytes = rows_max * w * 3
-        key = (w, h, F, frame_parallel, G)
+        use_ex = (world > 1 or force_exchange) and not frame_parallel
+        letters = sorted(set(pattern)) if use_ex else ["A"]
+
+        def layout(letter):     # ranks that render row tiles, this rank's place among them (-1: none), its rows
+            G = world if (letter == "A" or frame_parallel) else world - 1
+            ridx = rank if G == world else rank - 1
+            return G, ridx, (h if frame_parallel else tiling.max_local_rows(h, tr, G))
+        key = (w, h, F, frame_parallel, tuple(letters))
         if buffers.get("key") != key:
             buffers.clear()
             buffers["key"] = key
-            if rank == 0 or frame_parallel:
-                n_local = len(frames_of_rank(F, rank, world)) if frame_parallel else F
-                buffers["frames_out"] = torch.empty((n_local, h, w, 3), dtype=torch.uint8, device=dev)
-            # N > 1: every rank renders its row tiles of the F frames of a batch into a slab; one gather per batch
+            buffers["lay"] = {}
+            # N > 1: every rank that renders puts its row tiles of the F frames of a batch into a slab; one gather per batch
             # moves the occupied tiles of the slabs to GPU 0, where one pass writes the frames in image order.
             # Pipelined: compaction, gather and placement of earlier batches overlap the render of later ones, and no
-            # rank's host waits for its own render (BatchExchange).  RT_BENCH_DENSE=1 sends whole slabs.
-            use_ex = (world > 1 or force_exchange) and not frame_parallel
-            if use_ex:
-                fo = buffers.get("frames_out")
-                if os.environ.get("RT_BENCH_DENSE"):
-                    buffers["ex"] = BatchExchange(F, slab_bytes, dev,
-                                                  lambda gathered, i: r.scatter_rows_frames(gathered[world - G:], G, w, h, tr, out=fo))
-                else:
-                    table = {}
-
-                    def place_tiles(entries, counts, i):
-                        # (RCCL: called with the exchange's side stream current — the placement runs beside later renders)
-                        # (a root that does not render has no entries: the renderers' are ranks 1 .. N - 1 of the gather)
-                        table["t"] = r.place_tiles(entries[world - G:], counts[world - G:], w, h, tr, fo, table.get("t"),
-                                                   on_current_stream=buffers["ex"].on_side)
-                    buffers["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
-                                                  capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
-                                                  force_collectives=force_exchange, comm=comm, contributes=renders_here)
-        ex = buffers.get("ex")
-        frames_out = buffers.get("frames_out")
+            # rank's host waits for its own render (BatchExchange).  RT_BENCH_DENSE=1 sends whole slabs.  Each layout has
+            # its own exchange (slabs of its size) and its own frames on the root.
+            for letter in letters:
+                G, ridx, rows_max = layout(letter)
+                L = dict(G=G, ridx=ridx, rows_max=rows_max, ex=None, fo=None, count=0)
+                if rank == 0 or frame_parallel:
+                    n_local = len(frames_of_rank(F, rank, world)) if frame_parallel else F
+                    L["fo"] = torch.empty((n_local, h, w, 3), dtype=torch.uint8, device=dev)
+                if use_ex:
+                    slab_bytes = rows_max * w * 3
+                    if os.environ.get("RT_BENCH_DENSE"):
+                        L["ex"] = BatchExchange(F, slab_bytes, dev,
+                                                lambda gathered, i, L=L: r.scatter_rows_frames(gathered[world - L["G"]:], L["G"], w, h, tr, out=L["fo"]))
+                    else:
+                        def place_tiles(entries, counts, i, L=L, table={}):
+                            # (called with the stream current on which the placement is to run: the exchange's side stream, or —
+                            # where the root renders in this layout — its render stream; a root that does not render has no
+                            # entries: the renderers' are ranks 1 .. N - 1 of the gather)
+                            table["t"] = r.place_tiles(entries[world - L["G"]:], counts[world - L["G"]:], w, h, tr, L["fo"], table.get("t"),
+                                                       on_current_stream=L["ex"].on_side)
+                        L["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
+                                                capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
+                                                force_collectives=force_exchange, comm=comm, contributes=ridx >= 0)
+                buffers["lay"][letter] = L
+        lay = buffers["lay"]
+        exs = [L["ex"] for L in lay.values() if L["ex"] is not None]
+        seq = pattern if use_ex else "A"
+        # (averages over the pattern, for the per-launch figures below)
+        rows_max = max(L["rows_max"] for L in lay.values())
+        rows_mean = sum(lay[c]["rows_max"] for c in seq) / len(seq)
+        renders_here = any(L["ridx"] >= 0 for L in lay.values())
+        render_share = sum(1 for c in seq if lay[c]["ridx"] >= 0) / len(seq)     # of the batches, on this rank
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
         cams = [Camera()] * F                       # config 2's fixed pinhole; frames differ by seed
@@ -335,24 +357,28 @@ def main():
         def step(i, timed_idx=None):
             for b in range(B):                      # batch number j: its frames are j F .. (j + 1) F - 1 of the run
                 j = i * B + b
+                L = lay[seq[j % len(seq)]]
+                ex = L["ex"]
                 if timed_idx is not None and b == 0:
                     ev[timed_idx][0].record()
-                if not renders_here:                # (the root at N >= 3: it gathers and places)
+                k = L["count"]                      # (each layout's exchange counts its own batches)
+                L["count"] += 1
+                if L["ridx"] < 0:                   # (layout B on the root: it gathers and places)
                     pass
-                elif frame_parallel:                  # this rank's frames of the batch, whole
-                    r.render_frames(cams, [j * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=frames_out)
+                elif frame_parallel:                # this rank's frames of the batch, whole
+                    r.render_frames(cams, [j * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=L["fo"])
                 else:
                     # N = 1: the rank owns every row, so its packed slab IS the frame batch
-                    out = frames_out if ex is None else ex.slab(j).view(F, rows_max, w, 3)
+                    out = L["fo"] if ex is None else ex.slab(k).view(F, L["rows_max"], w, 3)
                     r.render_frames(cams, range(j * F, (j + 1) * F), w, h, samples, max_depth=D, rng_mode="K",
-                                    out=out, tile_rows=tr, tile_first=ridx, tile_stride=G)
+                                    out=out, tile_rows=tr, tile_first=L["ridx"], tile_stride=L["G"])
                 if timed_idx is not None and b == B - 1:
                     ev[timed_idx][1].record()
                 if ex is not None:
-                    ex.submit(j)
+                    ex.submit(k)
 
         def barrier():
-            if ex is not None:
+            for ex in exs:
                 ex.drain()         # the last batches' gathers and placements belong to the timed region
             if world > 1:
                 dist.barrier()
@@ -362,7 +388,7 @@ def main():
             step(i)
         barrier()
         r.reset_ray_counts()
-        if ex is not None:
+        for ex in exs:
             ex.sent_bytes = 0
         barrier()
         t0 = time.perf_counter()
@@ -374,7 +400,7 @@ def main():
         gather_ms = None
         if frame_parallel:                          # config 5: the one exchange, after the clock has stopped
             t1 = time.perf_counter()
-            gather_frames(frames_out, F)
+            gather_frames(lay["A"]["fo"], F)
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -393,7 +419,9 @@ def main():
         launches_per_step = B * -(-n_local_frames // per_launch) * (1 if one_stream_launch else samples)
         # (with several batches per step the events also cover the other stream-ordered work between the pairs: the
         # exchange's compaction kernels at N > 1)
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (steps * launches_per_step) if renders_here else 0.0
+        # (a rank that sits out some batches of the pattern — the root — reports no launch time: its events span the batches it
+        # only places; the busiest rank's is taken below)
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (steps * launches_per_step) if render_share == 1.0 else 0.0
         # (launch time, rays and shaded hits of the busiest rank: what the per-launch figures of the roofline block are about —
         # rank 0's own where it renders alone)
         kmax = torch.tensor([kern_ms, rc["total"], rc["shaded_hits"]], dtype=torch.float64, device=red_dev)
@@ -434,17 +462,18 @@ def main():
             roof["issue_frac"] = (pmc["valu"] + pmc["salu"]) * scale / secs / ISSUE_SLOTS_PER_S
             roof["valu_issue_frac"] = pmc["valu"] * scale / secs / ISSUE_SLOTS_PER_S
             roof["traffic"] = pmc["hbm_bytes"] * scale
-            roof["frame_bytes_per_launch"] = float(n_local_frames) * rows_max * w * 3
+            roof["frame_bytes_per_launch"] = float(n_local_frames) * rows_mean * w * 3
             roof["pmc_profile"] = pmc["profile"]
             roof["pmc_note"] = ("issue_frac = (vector + scalar wave-instructions) / (1024 SIMDs x 1.2e9 issue slots/s: one wave64 "
                                 "instruction per 2 clocks); traffic = HBM bytes per launch pair (TCC_EA0_*); PMC counts per ray from "
                                 "the named profile of this workload, scaled by this run's rays")
         if frame_parallel:
             par = f"frame-parallel x{world}: frame f -> rank f mod {world}, whole frames, one gather after the timed region"
-        elif world > 1 or ex is not None:
-            par = f"row-tiles x{G} (tile {tr} rows" + ("" if G == world else f"; GPU 0 of {world} gathers and places, it does not render") + \
-                  ") + RCCL gather to GPU 0" + \
-                  (" of the occupied 8x8 tiles" if ex is not None and ex.sparse else "") + \
+        elif exs:
+            kinds = {"A": f"A = all {world} ranks render, tile t -> rank t mod {world}",
+                     "B": f"B = ranks 1..{world - 1} render, tile t -> rank 1 + t mod {world - 1}, GPU 0 gathers and places only"}
+            par = f"row tiles of {tr} rows, layouts by batch in the pattern {seq!r} (" + "; ".join(kinds[c] for c in sorted(set(seq))) + \
+                  ") + RCCL gather to GPU 0" + (" of the occupied 8x8 tiles" if exs[0].sparse else "") + \
                   (" (a group of ONE rank: rehearsal of the N > 1 step)" if world == 1 else "")
         else:
             par = "single GPU"
@@ -460,7 +489,7 @@ def main():
             "mpixels_per_s": primary / dt / 1e6,
             "frames_per_s": steps * F * B / dt,
             "timed_region_s": dt,
-            "exchange_bytes_per_step_rank0": (ex.sent_bytes / steps) if ex is not None else 0,
+            "exchange_bytes_per_step_rank0": sum(ex.sent_bytes for ex in exs) / steps,
             "roofline": roof,
         }
         if gather_ms is not None:

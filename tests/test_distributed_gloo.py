@@ -293,6 +293,73 @@ def test_batch_exchange_with_a_root_that_only_places(sparse):
     assert ok == [True] * 4
 
 
+def _gpu_mixed_layouts_worker(rank, world, port, q, pattern):
+    """bench.py's N > 1 loop with two layouts taking turns (A: all ranks render; B: the root only places), each with an
+    exchange of its own: every batch must come out as the whole-frame render of its frames."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import tiling
+        from raytracer_amd.distributed import BatchExchange
+        from raytracer_amd.render import Renderer
+        from raytracer_amd.scenes import generate_scene, orbit_camera
+        w, h, tr, F, steps = 320, 187, 8, 4, 7
+        r = Renderer(0)
+        r.upload_scene(generate_scene(8, 1, keep_default=True))
+        ok = []
+        lay = {}
+        for letter in sorted(set(pattern)):
+            G, ridx = (world, rank) if letter == "A" else (world - 1, rank - 1)
+            L = dict(G=G, ridx=ridx, rows_max=tiling.max_local_rows(h, tr, G), count=0, batch_of={},
+                     fo=torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0"))
+
+            def place_tiles(entries, counts, k, L=L):
+                L["fo"].fill_(77)
+                r.place_tiles(entries[world - L["G"]:], counts[world - L["G"]:], w, h, tr, L["fo"])
+                i = L["batch_of"][k]
+                cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+                ok.append((i, bool(torch.equal(L["fo"], r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)))))
+
+            L["ex"] = BatchExchange(F, L["rows_max"] * w * 3, "cuda:0", None, compact=r.compact_tiles, place_tiles=place_tiles,
+                                    capacity=F * (((w + 7) // 8) | 1) * ((L["rows_max"] + 7) // 8), contributes=ridx >= 0)
+            lay[letter] = L
+        for i in range(steps):
+            L = lay[pattern[i % len(pattern)]]
+            k = L["count"]; L["count"] += 1
+            L["batch_of"][k] = i
+            if L["ridx"] >= 0:
+                cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+                r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=L["ex"].slab(k).view(F, L["rows_max"], w, 3),
+                                tile_rows=tr, tile_first=L["ridx"], tile_stride=L["G"])
+            L["ex"].submit(k)
+        for L in lay.values():
+            L["ex"].drain()
+        if rank == 0:
+            q.put(sorted(ok))
+        r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,pattern", [(2, "AAB"), (3, "AB")])
+def test_batch_exchange_with_layouts_taking_turns(world, pattern):
+    """bench.py gives the root a part share of the rendering by letting two layouts take turns, batch by batch, each with
+    its own exchange: all seven batches arrive byte-identical to whole-frame renders."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_mixed_layouts_worker, args=(r, world, port, q, pattern)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(170)
+        assert p.exitcode == 0
+    ok = q.get(timeout=5)
+    assert ok == [(i, True) for i in range(7)]
+
+
 @pytest.mark.gpu
 def test_batch_exchange_of_a_refractive_scene():
     """The same exchange on a scene with glass: a refractive frame is summed with float atomics, so the assembled

@@ -3,9 +3,9 @@
 rt_compact_tiles of its slab, the bytes a rank hands to the gather, and rt_place_tiles of all N ranks' entries on the root
 (every rank's share is rendered here, one after another, to have real entries).  Model of the steady state of the
 pipelined exchange (raytracer_amd/distributed.py): a batch leaves every
-    period(N) = max( render + compact [a rank that renders],  bytes per rank / link rate [each peer has its own xGMI link into
-                     GPU 0],  root: render + compact + place [N = 2: the placement runs behind the root's own render], place alone
-                     [N >= 3: the root does not render; N - 1 ranks share the row tiles] )
+    period(N) = max( render + compact [a rank that renders every batch],  bytes per rank / link rate [each peer has its own xGMI
+                     link into GPU 0],  root: its renders + compactions + the placement of EVERY batch ) averaged over bench.py's
+                     pattern of layouts (A: all N ranks render; B: ranks 1 .. N - 1 render, the root gathers and places only)
     python tools/scaling_model.py [workloads...] [--frames F (per batch; default 256, config 4: F / 16)] > profiles/r3_scaling_model.txt"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -38,23 +38,24 @@ for wl in (workloads or ["c2", "t64", "c4"]):
     r.upload_scene(bench.build_scene(wl))
     cams = r.pack_cameras([Camera()] * F)
     print(f"## {wl}: {desc}; batches of {F} frames, row tiles of {tr} rows")
-    print("| N | ranks that render | render share ms | compact ms | occupied tiles of the first renderer | MB per rank | link ms @153 GB/s | "
-          "place ms (root) | renderers' period ms | root's period ms | bound | frames/s | speed-up |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| N | layouts by batch | render share ms A / B | compact ms A / B | MB per rank A / B | link ms @153 GB/s per batch | "
+          "place ms (root) | renderers' work per batch ms | root's work per batch ms | bound | frames/s | speed-up |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     base = None
-    for N in (1, 2, 4, 8):
-        G = N if N < 3 else N - 1          # bench.py: from three GPUs on the root gathers and places, it does not render
+
+    def pieces(G, with_place):
+        """Layout with G ranks rendering: the first renderer's share and compaction, MB per rank, placement of all G ranks' entries."""
         rows_max = tiling.max_local_rows(h, tr, G)
         cap = F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8)
-        slabs = [torch.empty((F, rows_max, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(1)]
+        slab = torch.empty((F, rows_max, w, 3), dtype=torch.uint8, device="cuda:0")
         entries = torch.empty((G, cap, TILE_ENTRY_BYTES), dtype=torch.uint8, device="cuda:0")
         counts = torch.zeros(G, dtype=torch.int32, device="cuda:0")
         t_render = t_compact = None
         for rank in range(G):
             def render():
-                r.render_frames(cams, range(F), w, h, 1, max_depth=D, out=slabs[0], tile_rows=tr, tile_first=rank, tile_stride=G)
+                r.render_frames(cams, range(F), w, h, 1, max_depth=D, out=slab, tile_rows=tr, tile_first=rank, tile_stride=G)
             def compact():
-                r.compact_tiles(slabs[0], entries[rank], counts[rank:rank + 1])
+                r.compact_tiles(slab, entries[rank], counts[rank:rank + 1])
             if rank == 0:
                 t_render = timed(render)
                 render()
@@ -62,25 +63,36 @@ for wl in (workloads or ["c2", "t64", "c4"]):
             else:
                 render(); compact()
         torch.cuda.synchronize()
-        cnt = [int(c) for c in counts.tolist()]
-        nmax = max(cnt)
-        gathered = entries[:, :max(nmax, 1)].contiguous()
-        out = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0")
-        table = {}
-        def place():
-            table["t"] = r.place_tiles(gathered, counts, w, h, tr, out, table.get("t"))
-        t_place = timed(place) if N > 1 else 0.0
-        mb = nmax * TILE_ENTRY_BYTES / 1e6
-        t_link = mb / 1e3 / LINK_GBS * 1e3 if N > 1 else 0.0
-        work = t_render + (t_compact if N > 1 else 0.0)      # (a single GPU renders into the frames: no exchange)
-        root = work + t_place if G == N else t_place          # (placement behind the root's own render: tools/root_emulation.py)
-        period = max(work, t_link, root)
-        bound = "link" if period == t_link else "root (render + placement)" if (period == root and G == N and N > 1) else \
-                "root (placement)" if period == root and N > 1 else "render"
+        nmax = max(int(c) for c in counts.tolist())
+        t_place = 0.0
+        if with_place:
+            gathered = entries[:, :max(nmax, 1)].contiguous()
+            out = torch.empty((F, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            table = {}
+            def place():
+                table["t"] = r.place_tiles(gathered, counts, w, h, tr, out, table.get("t"))
+            t_place = timed(place)
+            del gathered, out
+        del slab, entries
+        torch.cuda.empty_cache()
+        return t_render, t_compact, nmax * TILE_ENTRY_BYTES / 1e6, t_place
+
+    for N in (1, 2, 4, 8):
+        # bench.py's pattern of layouts, one letter per batch: A = all N ranks render, B = ranks 1 .. N - 1 render and the root
+        # gathers and places only
+        pattern = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"}.get(N, "B")
+        pc = {c: pieces(N if c == "A" else N - 1, N > 1) for c in sorted(set(pattern))}
+        nA, nB, n = pattern.count("A"), pattern.count("B"), len(pattern)
+        ex = N > 1                                            # (a single GPU renders into the frames: no exchange)
+        work = sum(pc[c][0] + (pc[c][1] if ex else 0.0) for c in pattern) / n                 # a rank that renders every batch
+        root = (sum(pc["A"][0] + (pc["A"][1] if ex else 0.0) for _ in range(nA)) + sum(pc[c][3] for c in pattern)) / n   # placement behind its renders
+        link = sum(pc[c][2] for c in pattern) / n / 1e3 / LINK_GBS * 1e3 if ex else 0.0      # (a peer's link, averaged over the pattern)
+        period = max(work, link, root)
+        bound = "render" if period == work else "link" if period == link else "root (its renders + every placement)"
         fs = F / period * 1e3
         if base is None: base = fs
-        print(f"| {N} | {G} | {t_render:.2f} | {t_compact:.2f} | {cnt[0]} | {mb:.1f} | {t_link:.2f} | {t_place:.2f} | {work:.2f} | {root:.2f} | "
+        def ab(i, fmt="{:.2f}"):
+            return " / ".join(fmt.format(pc[c][i]) if c in pc else "-" for c in "AB")
+        print(f"| {N} | {pattern} | {ab(0)} | {ab(1)} | {ab(2, '{:.1f}')} | {link:.2f} | {max(pc[c][3] for c in pc):.2f} | {work:.2f} | {root:.2f} | "
               f"{bound} | {fs:.0f} | {fs / base:.2f} |")
-        del slabs, entries, gathered, out
-        torch.cuda.empty_cache()
     print()
