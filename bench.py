@@ -8,8 +8,8 @@ BASELINE.json config 2 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per s
 index), inputs (scene) already resident on the GPU: 10 240 frames, ~125 ms per step, so that the default 20 timed steps
 last ~2.5 s and the clocks are at their steady state (a single batch takes 12 ms).  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
-(tile t -> the (t mod G)-th of the G ranks that render: all N, or — in some batches of a fixed pattern, in all from five GPUs
-on — ranks 1 .. N - 1 while GPU 0 only gathers and places; RT_BENCH_LAYOUTS overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
+(tile t -> the (t mod G)-th of the G ranks that render: both at N = 2, ranks 1 .. N - 1 from three GPUs on, where GPU 0 only
+gathers and places; RT_BENCH_LAYOUTS overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
 gather per batch moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
 raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_place_tiles writes the frames in image order:
 total work per step is fixed => "strong" scaling.  ``--workload c5`` at N > 1 is BASELINE config 5's mode
@@ -271,17 +271,16 @@ def main():
             else:
                 comm_note += " — rt_comm_* failed its self-test on some rank"
 
-    # Row tiles at N > 1: which ranks render, batch by batch.  GPU 0 writes every byte of every frame (rt_place_tiles: 0.56 ms
-    # per 256 1080p frames whatever N) and that does not hide behind its own render — the shading kernel fills the register
-    # file, a kernel of another stream runs behind it, not beside it (tools/root_emulation.py) — so a root with a full share
-    # is the slowest rank.  Two layouts take turns in a fixed pattern, one letter per batch:
+    # Row tiles at N > 1: which ranks render.  GPU 0 writes every byte of every frame (rt_place_tiles: 0.56 ms per 256 1080p
+    # frames whatever N) and that does not hide behind its own render — the shading kernel fills the register file, a
+    # kernel of another stream runs behind it, not beside it (tools/root_emulation.py) — so a root with a full share is the
+    # slowest rank from N = 3 on.  Two layouts, one letter per batch of a repeating pattern:
     #   A — all N ranks render, tile t -> rank t mod N;      B — ranks 1 .. N - 1 render, tile t -> rank 1 + t mod (N - 1),
     #                                                            the root gathers and places only.
-    # The pattern gives the root the share of rendering that its placement leaves room for (from the pieces measured by
-    # tools/scaling_model.py: 5 of 6 batches at N = 2, 2 of 3 at N = 3, every other one at N = 4, none from N = 5 on).  The
-    # exchange is asynchronous, batches deep, so what counts is each rank's work summed over a pattern, not batch by batch.
-    # RT_BENCH_LAYOUTS=<letters> overrides (RT_BENCH_ROOT_RENDERS=1 / 0: "A" / "B").
-    pattern = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"}.get(world, "B")
+    # Default: "A" at N = 2 (half a frame is more than the placement costs), "B" from N = 3 on.  RT_BENCH_LAYOUTS=<letters>
+    # lets the layouts take turns (e.g. AAB: the root renders in two batches of three): that balances the ranks' work summed
+    # over a pattern, but pays only if the root's placements can wait for its idle batches — they cannot yet.
+    pattern = "A" if world < 3 else "B"
     if os.environ.get("RT_BENCH_ROOT_RENDERS") in ("0", "1"):
         pattern = "A" if os.environ["RT_BENCH_ROOT_RENDERS"] == "1" else "B"
     if os.environ.get("RT_BENCH_LAYOUTS"):

@@ -31,6 +31,9 @@ def timed(fn, reps=5):
 
 
 FRAMES = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
+# --patterns: RT_BENCH_LAYOUTS patterns that would balance the ranks (the root renders in some batches only) instead of bench.py's
+# defaults (A at N = 2, B from 3 on)
+PATTERNS = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"} if "--patterns" in sys.argv else None
 workloads = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--frames"]
 for wl in (workloads or ["c2", "t64", "c4"]):
     w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
@@ -80,7 +83,7 @@ for wl in (workloads or ["c2", "t64", "c4"]):
     for N in (1, 2, 4, 8):
         # bench.py's pattern of layouts, one letter per batch: A = all N ranks render, B = ranks 1 .. N - 1 render and the root
         # gathers and places only
-        pattern = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"}.get(N, "B")
+        pattern = PATTERNS.get(N, "B") if PATTERNS else ("A" if N < 3 else "B")
         pc = {c: pieces(N if c == "A" else N - 1, N > 1) for c in sorted(set(pattern))}
         nA, nB, n = pattern.count("A"), pattern.count("B"), len(pattern)
         ex = N > 1                                            # (a single GPU renders into the frames: no exchange)
