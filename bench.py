@@ -279,7 +279,8 @@ def main():
     #                                                            the root gathers and places only.
     # Default: "A" at N = 2 (half a frame is more than the placement costs), "B" from N = 3 on.  RT_BENCH_LAYOUTS=<letters>
     # lets the layouts take turns (e.g. AAB: the root renders in two batches of three): that balances the ranks' work summed
-    # over a pattern, but pays only if the root's placements can wait for its idle batches — they cannot yet.
+    # over a pattern; the root then places everything gathered so far at the start of each B batch, on its render stream
+    # (BatchExchange(defer_place=True)).  Not the default: no multi-GPU box to try it on.
     pattern = "A" if world < 3 else "B"
     if os.environ.get("RT_BENCH_ROOT_RENDERS") in ("0", "1"):
         pattern = "A" if os.environ["RT_BENCH_ROOT_RENDERS"] == "1" else "B"
@@ -333,7 +334,11 @@ def main():
                                                        on_current_stream=L["ex"].on_side)
                         L["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
                                                 capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
-                                                force_collectives=force_exchange, comm=comm, contributes=ridx >= 0)
+                                                force_collectives=force_exchange, contributes=ridx >= 0,
+                                                # (layouts taking turns: the root places when it is idle — deferred placement, which
+                                                # has only run on torch.distributed's collectives: with the library's communicator
+                                                # the group-of-one rehearsal of it hangs in the count exchange, cause not found)
+                                                comm=None if len(letters) > 1 else comm, defer_place=len(letters) > 1)
                 buffers["lay"][letter] = L
         lay = buffers["lay"]
         exs = [L["ex"] for L in lay.values() if L["ex"] is not None]
@@ -363,7 +368,10 @@ def main():
                 k = L["count"]                      # (each layout's exchange counts its own batches)
                 L["count"] += 1
                 if L["ridx"] < 0:                   # (layout B on the root: it gathers and places)
-                    pass
+                    # layouts taking turns: this is the root's idle batch — everything gathered so far is placed now, on the
+                    # render stream, which has nothing else to do until the next A batch
+                    for e in exs:
+                        e.place_pending()
                 elif frame_parallel:                # this rank's frames of the batch, whole
                     r.render_frames(cams, [j * F + int(f) for f in mine], w, h, samples, max_depth=D, rng_mode="K", out=L["fo"])
                 else:

@@ -107,6 +107,8 @@ class BatchExchange:
     GPUs on) —: it joins every collective with a count of zero and ``compact`` is not called.
     ``place_beside``: True = the root's placement runs on the side stream, False = on the render stream once the gather has
     landed; default: beside only where the root does not render (``contributes`` False).
+    ``defer_place`` (sparse mode): the pipeline gathers but does not place; ``place_pending()`` places what has been gathered
+    so far on the stream current at that call (``drain()`` does too).
     ``comm``: a Renderer that holds a communicator (Renderer.comm_init): the two collectives of the sparse exchange are
     then the library's (rt_comm_all_gather_counts, rt_comm_gather — every rank sends exactly its own entries, nothing is
     padded to the largest rank), issued on the side stream; torch.distributed makes no call on the data path.
@@ -114,7 +116,8 @@ class BatchExchange:
 
     def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0, *,
                  compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196,
-                 force_collectives: bool = False, comm=None, contributes: bool = True, place_beside: bool | None = None):
+                 force_collectives: bool = False, comm=None, contributes: bool = True, place_beside: bool | None = None,
+                 defer_place: bool = False):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
@@ -126,6 +129,11 @@ class BatchExchange:
         # renders too, on the render stream behind the gather: measured, a placement that competes with the root's own shading
         # kernel costs more than it hides (tools/root_emulation.py: config 4 at N = 2 6.1 ms per batch beside, 5.2 behind)
         self.place_beside = (not self.contributes) if place_beside is None else bool(place_beside)
+        # defer_place (sparse mode): a batch whose gather has been issued is not placed by the pipeline but kept until the
+        # caller says place_pending() — on the stream that is current then.  For a root that renders in some batches only and
+        # wants to place in the others, when its render stream has nothing else to do.
+        self.defer_place = bool(defer_place)
+        self.deferred = []               # (gathered, counts, step, event after the gather) of batches waiting for place_pending()
         if comm is not None:
             info = comm.comm_info()
             if compact is None or torch.device(device).type != "cuda":
@@ -302,6 +310,17 @@ class BatchExchange:
         if self.on_side:
             import torch
             behind = self.rank == self.dst and not self.place_beside
+            if self.defer_place and self.rank == self.dst:
+                with torch.cuda.stream(self.side):
+                    if st["work"] is not None:
+                        st["work"].wait()
+                    counts = st["counts"].clone()     # (counts_all[b3] is written again three batches on)
+                    done = torch.cuda.Event()
+                    done.record()
+                self.reusable[st["b3"]] = done        # entries[b3] is free once the gather has read it
+                self.deferred.append((st["gathered"], counts, step, done))
+                del self.stage[step]
+                return
             with torch.cuda.stream(self.side):
                 if st["work"] is not None:
                     st["work"].wait()
@@ -324,12 +343,33 @@ class BatchExchange:
             st["work"].wait()
         del self.stage[step]
         if self.rank == self.dst:
-            self.place_tiles(st["gathered"], st["counts"], step)
+            if self.defer_place:
+                self.deferred.append((st["gathered"], st["counts"].clone(), step, None))
+            else:
+                self.place_tiles(st["gathered"], st["counts"], step)
+
+    def place_pending(self):
+        """defer_place: place every batch whose gather has been issued, in order, on the CURRENT stream (which waits for each
+        gather to land).  Returns how many."""
+        if not self.deferred:
+            return 0
+        import torch
+        n = len(self.deferred)
+        for gathered, counts, step, done in self.deferred:
+            if done is not None:
+                main = torch.cuda.current_stream()
+                main.wait_event(done)
+                gathered.record_stream(main)          # (both were allocated on the side stream)
+                counts.record_stream(main)
+            self.place_tiles(gathered, counts, step)
+        self.deferred = []
+        return n
 
     def drain(self):
         if self.sparse:
             for step in sorted(self.stage):
                 self._place_stage(step)
+            self.place_pending()
             if self.on_side:
                 import torch
                 torch.cuda.current_stream().wait_stream(self.side)   # what follows on the render stream sees the frames

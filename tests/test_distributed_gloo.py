@@ -322,12 +322,18 @@ def _gpu_mixed_layouts_worker(rank, world, port, q, pattern):
                 ok.append((i, bool(torch.equal(L["fo"], r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)))))
 
             L["ex"] = BatchExchange(F, L["rows_max"] * w * 3, "cuda:0", None, compact=r.compact_tiles, place_tiles=place_tiles,
-                                    capacity=F * (((w + 7) // 8) | 1) * ((L["rows_max"] + 7) // 8), contributes=ridx >= 0)
+                                    capacity=F * (((w + 7) // 8) | 1) * ((L["rows_max"] + 7) // 8), contributes=ridx >= 0,
+                                    defer_place=True)
             lay[letter] = L
         for i in range(steps):
             L = lay[pattern[i % len(pattern)]]
             k = L["count"]; L["count"] += 1
             L["batch_of"][k] = i
+            if L["ridx"] < 0:                    # (the root's idle batch: it places what has been gathered so far)
+                before = len(ok)
+                for M in lay.values():
+                    M["ex"].place_pending()
+                assert i < 5 or len(ok) > before      # (an exchange places two of its own submits behind)
             if L["ridx"] >= 0:
                 cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
                 r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=L["ex"].slab(k).view(F, L["rows_max"], w, 3),

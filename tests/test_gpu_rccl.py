@@ -84,6 +84,28 @@ def _worker(port, q):
             ok.append(bool(torch.equal(kept[i], full)) and bool(full.any()))
         res["exchange"] = ok
         res["sent_bytes"] = int(ex.sent_bytes)
+        # ---- the same with deferred placement: the pipeline gathers, the caller places (every third batch here, and at drain)
+        kept.clear()
+        exd = BatchExchange(F, rows_max * w * 3, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
+                            capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), force_collectives=True, defer_place=True)
+        placed_at = []
+        for i in range(steps):
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=exd.slab(i).view(F, rows_max, w, 3),
+                            tile_rows=tr, tile_first=0, tile_stride=1)
+            exd.submit(i)
+            if i % 3 == 2:
+                placed_at.append(exd.place_pending())
+        res["deferred_nothing_early"] = len(kept) == sum(placed_at)
+        exd.drain()
+        torch.cuda.synchronize()
+        okd = []
+        for i in range(steps):
+            cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+            full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
+            okd.append(i in kept and bool(torch.equal(kept[i], full)))
+        res["deferred_exchange"] = okd
+        res["deferred_batches"] = placed_at
         # ---- config 5's one gather at the end (world 1: a copy), and the dense exchange's gather
         res["gather_frames"] = bool(torch.equal(gather_frames(full, F), full))
         seen = []
@@ -109,6 +131,7 @@ def test_rccl_group_of_one_runs_the_exchange():
     assert res["backend"] == "nccl" and res["on_side"]
     assert res["all_gather_into_tensor"] and res["gather_into_views"] and res["all_reduce_barrier"]
     assert res["exchange"] == [True] * 7 and res["sent_bytes"] > 0
+    assert res["deferred_nothing_early"] and res["deferred_exchange"] == [True] * 7 and sum(res["deferred_batches"]) >= 3, res
     assert res["gather_frames"] and res["dense_world1"]
     assert p.exitcode == 0
 
@@ -121,6 +144,8 @@ def _worker_abi(q):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     res = {}
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)      # (a hang ends here, with the stack on stderr, not at the harness's limit)
     try:
         from raytracer_amd import _lib, tiling
         from raytracer_amd.distributed import BatchExchange
