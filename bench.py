@@ -334,11 +334,9 @@ def main():
                                                        on_current_stream=L["ex"].on_side)
                         L["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
                                                 capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
-                                                force_collectives=force_exchange, contributes=ridx >= 0,
-                                                # (layouts taking turns: the root places when it is idle — deferred placement, which
-                                                # has only run on torch.distributed's collectives: with the library's communicator
-                                                # the group-of-one rehearsal of it hangs in the count exchange, cause not found)
-                                                comm=None if len(letters) > 1 else comm, defer_place=len(letters) > 1)
+                                                force_collectives=force_exchange, comm=comm, contributes=ridx >= 0,
+                                                # (layouts taking turns: the root places when it is idle)
+                                                defer_place=len(letters) > 1)
                 buffers["lay"][letter] = L
         lay = buffers["lay"]
         exs = [L["ex"] for L in lay.values() if L["ex"] is not None]
@@ -505,11 +503,20 @@ def main():
                                         "frames_per_s is at render completion (SURVEY.md 8e)")
         return out
 
-    res = measure(args.workload, args.frames, args.batches, args.steps, args.warmup, args.samples)
-    target = None
-    if not args.no_target and args.workload != "t64":
-        # the north-star target scene (1080p, depth 5, 64 spheres): the same step, the same number of steps
-        target = measure("t64", args.frames, args.batches, args.steps, 1, 1)
+    # With an exchange, the render stream is a stream of its own, not HIP's legacy default stream (torch's current stream unless
+    # told otherwise): the default stream synchronises implicitly with every blocking stream of the process, and a default
+    # stream that waits for an event behind the library's ncclSend / ncclRecv deadlocked in the one-GPU rehearsal (deferred
+    # placement on the library's communicator) where an ordinary stream does not.
+    import contextlib
+    render_stream = torch.cuda.Stream(device=dev) if (world > 1 or force_exchange) else None
+    with (torch.cuda.stream(render_stream) if render_stream is not None else contextlib.nullcontext()):
+        r.use_torch_stream()
+        res = measure(args.workload, args.frames, args.batches, args.steps, args.warmup, args.samples)
+        target = None
+        if not args.no_target and args.workload != "t64":
+            # the north-star target scene (1080p, depth 5, 64 spheres): the same step, the same number of steps
+            target = measure("t64", args.frames, args.batches, args.steps, 1, 1)
+    r.use_torch_stream()
     single = None
     if rank == 0 and world == 1 and not args.no_single_frame and args.kernel == "stream":
         single = single_frame(r, args.workload)

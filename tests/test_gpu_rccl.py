@@ -208,6 +208,35 @@ def _worker_abi(q):
             ok.append(bool(torch.equal(kept[i], full)) and bool(full.any()))
         res["exchange"] = ok
         res["sent_bytes"] = int(ex.sent_bytes)
+        # ---- deferred placement on the library's collectives: the pipeline gathers, the caller places (every third batch and
+        # at drain) on ITS stream — a stream of its own here: on HIP's legacy default stream this very sequence deadlocks (the
+        # default stream waits for an event behind ncclSend / ncclRecv), which is why bench.py renders on a stream of its own
+        # whenever it exchanges
+        kept.clear()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            r.use_torch_stream()
+            exd = BatchExchange(F, rows_max * w * 3, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
+                                capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), force_collectives=True, comm=r,
+                                defer_place=True)
+            placed_at = []
+            for i in range(steps):
+                cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+                r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1, out=exd.slab(i).view(F, rows_max, w, 3),
+                                tile_rows=tr, tile_first=0, tile_stride=1)
+                exd.submit(i)
+                if i % 3 == 2:
+                    placed_at.append(exd.place_pending())
+            res["deferred_nothing_early"] = len(kept) == sum(placed_at)
+            exd.drain()
+            torch.cuda.synchronize()
+            okd = []
+            for i in range(steps):
+                cams = [orbit_camera(10 * i + f, 64) for f in range(F)]
+                full = r.render_frames(cams, range(i * F, (i + 1) * F), w, h, 1)
+                okd.append(i in kept and bool(torch.equal(kept[i], full)))
+        r.use_torch_stream()
+        res["deferred_exchange"] = okd
+        res["deferred_batches"] = placed_at
         r.comm_destroy()
         res["info_after"] = r.comm_info()
         r.comm_init_single()          # a context may join again; rt_destroy releases what it still holds
@@ -233,5 +262,6 @@ def test_library_communicator_group_of_one():
     assert res["info"]["n_ranks"] == 1 and res["info"]["rank"] == 0 and res["info"]["rccl_version"] >= 20700, res["info"]
     assert res["all_gather_counts"] and res["gather"], res
     assert res["on_side"] and res["exchange"] == [True] * 7 and res["sent_bytes"] > 0, res
+    assert res["deferred_nothing_early"] and res["deferred_exchange"] == [True] * 7 and sum(res["deferred_batches"]) >= 3, res
     assert res["info_after"]["n_ranks"] == 0
     assert p.exitcode == 0
