@@ -109,6 +109,10 @@ class BatchExchange:
     landed; default: beside only where the root does not render (``contributes`` False).
     ``defer_place`` (sparse mode): the pipeline gathers but does not place; ``place_pending()`` places what has been gathered
     so far on the stream current at that call (``drain()`` does too).
+    The render stream (torch's current stream when ``submit`` is called) should be a stream of its own, NOT HIP's legacy
+    default stream: that one synchronises implicitly with every blocking stream of the process, and made to wait for an event
+    behind the library's ncclSend / ncclRecv it deadlocked (bench.py: ``with torch.cuda.stream(torch.cuda.Stream())`` and
+    ``renderer.use_torch_stream()``).
     ``comm``: a Renderer that holds a communicator (Renderer.comm_init): the two collectives of the sparse exchange are
     then the library's (rt_comm_all_gather_counts, rt_comm_gather — every rank sends exactly its own entries, nothing is
     padded to the largest rank), issued on the side stream; torch.distributed makes no call on the data path.
