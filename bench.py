@@ -8,8 +8,8 @@ BASELINE.json config 2 (1920x1080, 8-sphere scene, depth 5, 13 shadow rays per s
 index), inputs (scene) already resident on the GPU: 10 240 frames, ~125 ms per step, so that the default 20 timed steps
 last ~2.5 s and the clocks are at their steady state (a single batch takes 12 ms).  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every frame is sharded by interleaved 8-row tiles
-(tile t -> the (t mod G)-th of the G ranks that render: both at N = 2, ranks 1 .. N - 1 from three GPUs on, where GPU 0 only
-gathers and places; RT_BENCH_LAYOUTS overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
+(tile t -> the (t mod G)-th of the G ranks that render: all N, or — in some batches of a fixed pattern, in all from five GPUs
+on — ranks 1 .. N - 1 while GPU 0 places what has been gathered; RT_BENCH_LAYOUTS overrides), each rank renders its tiles of all frames of the batch, and ONE RCCL
 gather per batch moves the occupied 8x8 tiles of the slabs (rt_compact_tiles: lossless, no host read-back, see
 raytracer_amd.distributed.BatchExchange) to GPU 0, where rt_place_tiles writes the frames in image order:
 total work per step is fixed => "strong" scaling.  ``--workload c5`` at N > 1 is BASELINE config 5's mode
@@ -277,11 +277,12 @@ def main():
     # slowest rank from N = 3 on.  Two layouts, one letter per batch of a repeating pattern:
     #   A — all N ranks render, tile t -> rank t mod N;      B — ranks 1 .. N - 1 render, tile t -> rank 1 + t mod (N - 1),
     #                                                            the root gathers and places only.
-    # Default: "A" at N = 2 (half a frame is more than the placement costs), "B" from N = 3 on.  RT_BENCH_LAYOUTS=<letters>
-    # lets the layouts take turns (e.g. AAB: the root renders in two batches of three): that balances the ranks' work summed
-    # over a pattern; the root then places everything gathered so far at the start of each B batch, on its render stream
-    # (BatchExchange(defer_place=True)).  Not the default: no multi-GPU box to try it on.
-    pattern = "A" if world < 3 else "B"
+    # The layouts take turns in a pattern that gives the root the share of rendering its placements leave room for: in an A
+    # batch every rank renders the same share and the root places NOTHING; at the start of each B batch the root places
+    # everything gathered so far on its render stream (BatchExchange(defer_place=True)) while the others render the B batch —
+    # about as long, by the pieces tools/scaling_model.py measures: AAAAAB at N = 2, AAB at 3, AB at 4, B alone from 5 on.
+    # RT_BENCH_LAYOUTS=<letters> overrides ("A" / "B": one layout throughout).
+    pattern = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"}.get(world, "B")
     if os.environ.get("RT_BENCH_ROOT_RENDERS") in ("0", "1"):
         pattern = "A" if os.environ["RT_BENCH_ROOT_RENDERS"] == "1" else "B"
     if os.environ.get("RT_BENCH_LAYOUTS"):
@@ -335,8 +336,11 @@ def main():
                         L["ex"] = BatchExchange(F, slab_bytes, dev, None, compact=r.compact_tiles, place_tiles=place_tiles,
                                                 capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8),
                                                 force_collectives=force_exchange, comm=comm, contributes=ridx >= 0,
+                                                side_stream=buffers.get("side"),
                                                 # (layouts taking turns: the root places when it is idle)
                                                 defer_place=len(letters) > 1)
+                if L["ex"] is not None and getattr(L["ex"], "on_side", False):
+                    buffers["side"] = L["ex"].side          # (one side stream for every layout's collectives)
                 buffers["lay"][letter] = L
         lay = buffers["lay"]
         exs = [L["ex"] for L in lay.values() if L["ex"] is not None]

@@ -107,6 +107,7 @@ class BatchExchange:
     GPUs on) —: it joins every collective with a count of zero and ``compact`` is not called.
     ``place_beside``: True = the root's placement runs on the side stream, False = on the render stream once the gather has
     landed; default: beside only where the root does not render (``contributes`` False).
+    ``side_stream``: the stream for the collectives (default: a high-priority stream of this exchange's own).
     ``defer_place`` (sparse mode): the pipeline gathers but does not place; ``place_pending()`` places what has been gathered
     so far on the stream current at that call (``drain()`` does too).
     The render stream (torch's current stream when ``submit`` is called) should be a stream of its own, NOT HIP's legacy
@@ -121,7 +122,7 @@ class BatchExchange:
     def __init__(self, n_frames: int, slab_bytes: int, device, place, group=None, dst: int = 0, *,
                  compact=None, place_tiles=None, capacity: int | None = None, entry_bytes: int = 196,
                  force_collectives: bool = False, comm=None, contributes: bool = True, place_beside: bool | None = None,
-                 defer_place: bool = False):
+                 defer_place: bool = False, side_stream=None):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.place = dist, group, dst, place
@@ -166,7 +167,10 @@ class BatchExchange:
                 # placement queue up BEHIND the renders instead of running beside them (seen in a kernel trace: both on queue 4,
                 # strictly one after the other).  And a placement is short, memory-bound work that should not wait for a
                 # persistent shading kernel to drain.
-                self.side = torch.cuda.Stream(device=device, priority=int(os.environ.get("RT_EXCHANGE_STREAM_PRIORITY", "-1")))
+                # (``side_stream``: exchanges that share a communicator share the side stream too, so that the collectives reach
+                # the communicator in ONE stream's order)
+                self.side = side_stream if side_stream is not None else \
+                    torch.cuda.Stream(device=device, priority=int(os.environ.get("RT_EXCHANGE_STREAM_PRIORITY", "-1")))
                 self.counts_all = [torch.zeros(self.world, dtype=torch.int32, device=device) for _ in range(3)]
                 self.counts_host = [torch.zeros(self.world, dtype=torch.int32).pin_memory() for _ in range(3)]
                 self.reusable = [None, None, None]   # event on the side stream: the gather that read entries[b] is done

@@ -31,9 +31,8 @@ def timed(fn, reps=5):
 
 
 FRAMES = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
-# --patterns: RT_BENCH_LAYOUTS patterns that would balance the ranks (the root renders in some batches only) instead of bench.py's
-# defaults (A at N = 2, B from 3 on)
-PATTERNS = {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"} if "--patterns" in sys.argv else None
+# bench.py's patterns of layouts (the root renders in some batches only); --plain: one layout throughout (A at N = 2, B from 3 on)
+PATTERNS = None if "--plain" in sys.argv else {1: "A", 2: "AAAAAB", 3: "AAB", 4: "AB"}
 workloads = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--frames"]
 for wl in (workloads or ["c2", "t64", "c4"]):
     w, h, n, _, _, D, desc = bench.WORKLOADS[wl]
