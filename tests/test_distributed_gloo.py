@@ -59,7 +59,7 @@ def test_gather_row_tiles_gloo(world, w, h, tile_rows):
     assert ok and frames_ok and (nonblack or h < 8)
 
 
-def _sparse_exchange_worker(rank, world, port, q, root_places_only=False):
+def _sparse_exchange_worker(rank, world, port, q, root_places_only=False, defer=False):
     """BatchExchange's sparse pipeline on CPU tensors: mostly black slabs with a different number of lit tiles on
     every rank and step (also none at all); compact / place_tiles are the numpy stand-ins of tests/tile_exchange_ref
     (the HIP entry points need a GPU: tests below)."""
@@ -113,12 +113,17 @@ def _sparse_exchange_worker(rank, world, port, q, root_places_only=False):
             placed.append((step, bool(np.array_equal(got, exp))))
 
         ex = BatchExchange(F, rows_max * w * 3, "cpu", None, compact=compact, place_tiles=place_tiles,
-                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), contributes=ridx >= 0)
+                           capacity=F * (((w + 7) // 8) | 1) * ((rows_max + 7) // 8), contributes=ridx >= 0,
+                           defer_place=defer)
         assert ex.sparse
         for i in range(steps):
             if ridx >= 0:
                 ex.slab(i).copy_(torch.from_numpy(slab_of(i, ridx)).view(F, -1))
             ex.submit(i)
+            if defer:                    # (the pipeline gathers; nothing is placed until the caller asks)
+                assert len(placed) == (i // 3) * 3 - 2 * (i >= 3) or rank != 0 or i < 3
+                if i % 3 == 2:
+                    ex.place_pending()
         ex.drain()
         assert ex.sent_bytes < steps * F * rows_max * w * 3 / 2      # (dense: the whole slabs)
         if rank == 0:
@@ -171,15 +176,16 @@ def test_batch_exchange_pipeline_gloo(world):
     assert [s for s, _ in placed] == list(range(7)) and all(ok for _, ok in placed)
 
 
-@pytest.mark.parametrize("world,root_places_only", [(2, False), (3, False), (3, True)])
-def test_sparse_batch_exchange_gloo(world, root_places_only):
+@pytest.mark.parametrize("world,root_places_only,defer", [(2, False, False), (3, False, False), (3, True, False), (2, False, True),
+                                                          (3, True, True)])
+def test_sparse_batch_exchange_gloo(world, root_places_only, defer):
     """BatchExchange's sparse mode: only occupied tiles travel, three pipelined stages; the root assembles the
-    same frames — also where it renders nothing itself (bench.py's layout from three GPUs on: the other ranks share the
-    row tiles, rank 0 joins with no entries)."""
+    same frames — also where it renders nothing itself (bench.py's layout B: the other ranks share the row tiles, rank 0
+    joins with no entries), and with deferred placement (the caller says when: place_pending())."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, world, port, q, root_places_only)) for r in range(world)]
+    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, world, port, q, root_places_only, defer)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
