@@ -448,10 +448,12 @@ def test_samples_in_one_launch_change_no_byte(renderer):
 
 def test_stream_and_pixel_kernels_agree(renderer):
     """The work-queue kernel reorders work, never arithmetic: byte-identical to the one-thread-per-
-    pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes."""
+    pixel kernel, for 1 and 3 samples, ragged sizes, both RNG modes — also at heights of 4, 8 and 16 region rows of 48 pixels,
+    where the visibility pass rotates the region rows over the XCDs."""
     import torch
     for scene, (w, h), D in ((generate_scene(64, 2), (1920, 1080), 5), (generate_scene(8, 1, keep_default=True), (333, 187), 8),
-                             (default_scene(), (64, 33), 3)):
+                             (default_scene(), (64, 33), 3), (generate_scene(8, 1, keep_default=True), (130, 384), 5),
+                             (generate_scene(150, 7), (70, 768), 4)):
         renderer.upload_scene(scene)
         for spp, mode in ((1, "K"), (3, "K"), (2, "C")):
             renderer.set_kernel("pixel")
